@@ -1,0 +1,132 @@
+/*
+ * ogdewarp.h — C ABI of libogdewarp.so: the MI355X (gfx950) dewarp hot path of Origami.
+ *
+ * The reference (poke1024/origami) has no FFI for this path; the seam is the set of third-party
+ * calls inside origami/core/dewarp.py and origami/core/lingrid.py.  Every entry point below
+ * replaces one of those call sites (cited as `ref:` = file:line under the reference tree).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / numpy types.
+ *  - every function returns OGD_OK (0) or a negative ogd_status; the message of the last failure
+ *    on the calling thread is returned by ogd_last_error().  Nothing here aborts the process.
+ *  - "host" entry points take host buffers (C-contiguous unless a stride is passed), stage them
+ *    through device memory owned by the library, and return when the result is in the host buffer.
+ *  - "*_dev" entry points take DEVICE pointers plus a hipStream_t (passed as void*, NULL = the
+ *    null stream) and only enqueue work: the caller synchronises.  They allocate nothing.
+ *  - no HIP call happens before the first entry point is called (fork-safe: origami forks
+ *    its pool workers, ref: origami/batch/core/processor.py:483).
+ *  - all entry points are thread-safe; handles (ogd_tri) are immutable after creation.
+ */
+#ifndef OGDEWARP_H
+#define OGDEWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ogd_status {
+  OGD_OK = 0,
+  OGD_ERR_INVALID = -1,  /* bad argument (shape, null pointer, unsupported channel count ...) */
+  OGD_ERR_HIP = -2,      /* a HIP runtime call failed; ogd_last_error() has hipGetErrorString */
+  OGD_ERR_NOMEM = -3,    /* host or device allocation failed */
+  OGD_ERR_NODEVICE = -4  /* no gfx950 device visible */
+} ogd_status;
+
+#define OGD_INTER_NEAREST 0 /* cv2.INTER_NEAREST */
+#define OGD_INTER_LINEAR 1  /* cv2.INTER_LINEAR  */
+
+/* ---- library / device plumbing (no reference counterpart: the reference is CPU-only) ---- */
+const char* ogd_last_error(void);
+int ogd_version(void);
+/* Number of visible GPUs (does not create a context). */
+int ogd_device_count(int* count);
+/* Bind the calling thread to `device` (-1: OGD_DEVICE env, else 0) and create its context. */
+int ogd_init(int device);
+int ogd_dev_alloc(void** dptr, size_t bytes);
+int ogd_dev_free(void* dptr);
+int ogd_memcpy_h2d(void* dptr, const void* hptr, size_t bytes, void* stream);
+int ogd_memcpy_d2h(void* hptr, const void* dptr, size_t bytes, void* stream);
+int ogd_stream_sync(void* stream);
+
+/* ---- K1a: dense sampling grid -------------------------------------------------------------
+ * ref: origami/core/dewarp.py:522-523  (cv2.resize(grid[:, :, c], (w*s, h*s), INTER_LINEAR) x2)
+ * nodes: [h][w][2] float32 (x, y); out: [h*s][w*s][2] float32.  OpenCV pixel-centre alignment,
+ * fp32 horizontal-then-vertical lerp.  sx, sy: the dewarp_image scale (ref: dewarp.py:622-623)
+ * applied in fp32 to a copy (1.0f = none).
+ */
+int ogd_grid_fill(const float* nodes, int h, int w, int s, float sx, float sy, float* out);
+int ogd_grid_fill_dev(const float* d_nodes, int h, int w, int s, float sx, float sy,
+                      float* d_out, void* stream);
+/* Same values sampled at dense pixels (ox*step, oy*step) only; out: [ceil(h*s/step)][ceil(w*s/step)][2].
+ * ref: origami/core/dewarp.py:557-559 (points("full")[::r, ::r]) without materialising the map. */
+int ogd_grid_points_strided(const float* nodes, int h, int w, int s, int step, float* out);
+
+/* ---- K2: remap ------------------------------------------------------------------------------
+ * ref: origami/core/dewarp.py:612-614 and :625-627  (cv2.remap(u8, map f32 (Hd,Wd,2), None, interp),
+ * BORDER_CONSTANT 0).  src: [H][W][C] uint8, C in {1,3,4}, row stride in bytes; map_xy: [Hd][Wd][2]
+ * float32 dense; dst: [Hd][Wd][C] uint8, row stride in bytes.  OpenCV fixed-point bilinear
+ * (1/32 px, 15-bit weights) or round-half-even nearest.
+ */
+int ogd_remap_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride,
+                 const float* map_xy, int Hd, int Wd,
+                 uint8_t* dst, ptrdiff_t dst_stride, int interp);
+int ogd_remap_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_stride,
+                     const float* d_map_xy, int Hd, int Wd,
+                     uint8_t* d_dst, ptrdiff_t dst_stride, int interp, void* stream);
+/* Fused K1a+K2: ref dewarp.py:608-627 as one pass; the dense map is never written to memory. */
+int ogd_dewarp_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride,
+                  const float* nodes, int h, int w, int s, float sx, float sy,
+                  uint8_t* dst, ptrdiff_t dst_stride, int interp);
+int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_stride,
+                      const float* d_nodes, int h, int w, int s, float sx, float sy,
+                      uint8_t* d_dst, ptrdiff_t dst_stride, int interp, void* stream);
+
+/* ---- K3 / K1b: piecewise-linear interpolation over a host Delaunay triangulation -------------
+ * ref: origami/core/lingrid.py:286-290 (scipy LinearNDInterpolator x2), :174-189 (clip + NaN merge),
+ *      :252-282 (dense variant, scipy griddata x2 + merge).
+ * pts: [n][2] float64; simplices: [nt][3] int32 (Qhull, host-side); transform: [nt][3][2] float64 =
+ * scipy Delaunay.transform (rows 0-1: inverse of the edge matrix, row 2: reference vertex), may be
+ * NULL (then computed here in fp64); vals: [n][nv] float64, nv in {1,2}.
+ */
+typedef struct ogd_tri ogd_tri;
+int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt,
+                   const double* transform, const double* vals, int nv, ogd_tri** out);
+int ogd_tri_destroy(ogd_tri* t);
+/* q: [nq][2] float64 -> out: [nq][nv] float64.  Points are clipped to bounds = {minx,miny,maxx,maxy}
+ * (NULL = no clip), looked up in `inner` (may be NULL) and, where that yields NaN, in `extra`. */
+int ogd_tri_eval(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                 const double* q, int64_t nq, double* out);
+int ogd_tri_eval_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                     const double* d_q, int64_t nq, double* d_out, void* stream);
+/* Ragged batch: ring r owns points offsets[r] .. offsets[r+1]-1; one wavefront per ring.
+ * ref: origami/batch/detect/dewarp.py:26 (shapely.ops.transform -> one Transformer call per ring). */
+int ogd_tri_eval_ragged(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                        const double* q, const int64_t* offsets, int nrings, double* out);
+int ogd_tri_eval_ragged_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                            const double* d_q, const int64_t* d_offsets, int nrings,
+                            double* d_out, void* stream);
+/* Dense variant on the lattice (x0 + ix*step, y0 + iy*step), ix < nx, iy < ny; component k of
+ * lattice point (ix, iy) is written to out[ix*stride_x + iy*stride_y + k] (strides in elements).
+ * out_f64 = 0: float32 output, 1: float64.  ref: origami/core/lingrid.py:257-277. */
+int ogd_tri_rasterize(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                      double x0, double y0, double step, int nx, int ny,
+                      void* out, int64_t stride_x, int64_t stride_y, int out_f64);
+int ogd_tri_rasterize_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                          double x0, double y0, double step, int nx, int ny,
+                          void* d_out, int64_t stride_x, int64_t stride_y, int out_f64,
+                          void* stream);
+
+/* ---- inverse point map ------------------------------------------------------
+ * ref: origami/core/dewarp.py:561-576 (scipy RegularGridInterpolator over the dense grid, linear,
+ * extrapolating).  q_yx: [nq][2] float64 (y, x) in dewarped pixels -> out_xy: [nq][2] float64 warped
+ * page position.  The dense grid is evaluated on the fly from the node grid (K1a arithmetic). */
+int ogd_grid_sample_bilinear(const float* nodes, int h, int w, int s,
+                             const double* q_yx, int64_t nq, double* out_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGDEWARP_H */

@@ -1,0 +1,288 @@
+"""ctypes binding of libogdewarp.so (include/ogdewarp.h).
+
+The library is the only compute path: there is no CPU fallback.  If the shared object is missing
+or no gfx950 device is visible, calls raise `OgdError` loudly.
+"""
+
+import ctypes
+import os
+from ctypes import (
+	POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_ssize_t, c_uint8,
+	c_void_p)
+from pathlib import Path
+
+import numpy as np
+
+INTER_NEAREST = 0  # == cv2.INTER_NEAREST
+INTER_LINEAR = 1  # == cv2.INTER_LINEAR
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libogdewarp.so"
+
+
+class OgdError(RuntimeError):
+	def __init__(self, status, message):
+		super().__init__("libogdewarp: %s (status %d)" % (message, status))
+		self.status = status
+
+
+_f32p = POINTER(c_float)
+_f64p = POINTER(c_double)
+_u8p = POINTER(c_uint8)
+_i32p = POINTER(c_int32)
+_i64p = POINTER(c_int64)
+
+# name -> (restype, argtypes); mirrors include/ogdewarp.h one to one
+SIGNATURES = {
+	"ogd_last_error": (c_char_p, []),
+	"ogd_version": (c_int, []),
+	"ogd_device_count": (c_int, [POINTER(c_int)]),
+	"ogd_init": (c_int, [c_int]),
+	"ogd_dev_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+	"ogd_dev_free": (c_int, [c_void_p]),
+	"ogd_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+	"ogd_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+	"ogd_stream_sync": (c_int, [c_void_p]),
+	"ogd_grid_fill": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+	"ogd_grid_fill_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+	"ogd_grid_points_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+	"ogd_remap_u8": (c_int, [
+		c_void_p, c_int, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_void_p, c_ssize_t, c_int]),
+	"ogd_remap_u8_dev": (c_int, [
+		c_void_p, c_int, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_void_p, c_ssize_t, c_int,
+		c_void_p]),
+	"ogd_dewarp_u8": (c_int, [
+		c_void_p, c_int, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_float, c_float,
+		c_void_p, c_ssize_t, c_int]),
+	"ogd_dewarp_u8_dev": (c_int, [
+		c_void_p, c_int, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_float, c_float,
+		c_void_p, c_ssize_t, c_int, c_void_p]),
+	"ogd_tri_create": (c_int, [
+		c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]),
+	"ogd_tri_destroy": (c_int, [c_void_p]),
+	"ogd_tri_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+	"ogd_tri_eval_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+	"ogd_tri_eval_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+	"ogd_tri_eval_ragged_dev": (c_int, [
+		c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+	"ogd_tri_rasterize": (c_int, [
+		c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int, c_int, c_void_p, c_int64,
+		c_int64, c_int]),
+	"ogd_tri_rasterize_dev": (c_int, [
+		c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int, c_int, c_void_p, c_int64,
+		c_int64, c_int, c_void_p]),
+	"ogd_grid_sample_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+	"""dlopen libogdewarp.so and type its exports.  Makes no HIP call (safe before fork)."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	path = Path(os.environ.get("OGDEWARP_LIB", LIB_PATH))
+	if not path.exists():
+		raise OgdError(-4, "%s is missing: build it with `python -m origami_amd.build`" % path)
+	lib = ctypes.CDLL(str(path))
+	for name, (restype, argtypes) in SIGNATURES.items():
+		fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+		fn.restype = restype
+		fn.argtypes = argtypes
+	_lib = lib
+	return lib
+
+
+def check(status):
+	if status != 0:
+		msg = load().ogd_last_error()
+		raise OgdError(status, msg.decode("utf8", "replace") if msg else "unknown error")
+
+
+def device_count():
+	n = c_int(0)
+	try:
+		check(load().ogd_device_count(ctypes.byref(n)))
+	except OgdError:
+		return 0
+	return n.value
+
+
+def init(device=-1):
+	check(load().ogd_init(int(device)))
+
+
+def _ptr(a):
+	return c_void_p(a.ctypes.data)
+
+
+def _c(a, dtype):
+	return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ---- K1a ------------------------------------------------------------------------------------------
+
+def grid_fill(nodes, cell, sx=1.0, sy=1.0):
+	"""(h, w, 2) float32 node grid -> (h*cell, w*cell, 2) float32 dense sampling grid."""
+	nodes = _c(nodes, np.float32)
+	if nodes.ndim != 3 or nodes.shape[2] != 2:
+		raise ValueError("nodes must have shape (h, w, 2)")
+	h, w = nodes.shape[:2]
+	out = np.empty((h * cell, w * cell, 2), dtype=np.float32)
+	check(load().ogd_grid_fill(_ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(out)))
+	return out
+
+
+def grid_points_strided(nodes, cell, step):
+	nodes = _c(nodes, np.float32)
+	h, w = nodes.shape[:2]
+	oh, ow = -(-h * cell // step), -(-w * cell // step)
+	out = np.empty((oh, ow, 2), dtype=np.float32)
+	check(load().ogd_grid_points_strided(_ptr(nodes), h, w, int(cell), int(step), _ptr(out)))
+	return out
+
+
+def grid_sample_bilinear(nodes, cell, q_yx):
+	nodes = _c(nodes, np.float32)
+	h, w = nodes.shape[:2]
+	q = _c(q_yx, np.float64).reshape(-1, 2)
+	out = np.empty_like(q)
+	check(load().ogd_grid_sample_bilinear(_ptr(nodes), h, w, int(cell), _ptr(q), len(q), _ptr(out)))
+	return out
+
+
+# ---- K2 -------------------------------------------------------------------------------------------
+
+def _image(a):
+	a = np.asarray(a)
+	if a.dtype != np.uint8:
+		raise TypeError("image must be uint8, got %s" % a.dtype)
+	if a.ndim == 2:
+		a = a[:, :, np.newaxis]
+		squeeze = True
+	elif a.ndim == 3:
+		squeeze = False
+	else:
+		raise ValueError("image must be (H, W) or (H, W, C)")
+	if a.strides[2] != 1 or a.strides[1] != a.shape[2] or a.strides[0] < a.shape[1] * a.shape[2]:
+		a = np.ascontiguousarray(a)
+	return a, squeeze
+
+
+def remap_u8(src, map_xy, interpolation=INTER_LINEAR):
+	"""cv2.remap(src, map_xy, None, interpolation) for uint8 sources, BORDER_CONSTANT 0."""
+	src, squeeze = _image(src)
+	map_xy = _c(map_xy, np.float32)
+	if map_xy.ndim != 3 or map_xy.shape[2] != 2:
+		raise ValueError("map must have shape (Hd, Wd, 2)")
+	H, W, C = src.shape
+	Hd, Wd = map_xy.shape[:2]
+	dst = np.empty((Hd, Wd, C), dtype=np.uint8)
+	check(load().ogd_remap_u8(
+		_ptr(src), H, W, C, src.strides[0], _ptr(map_xy), Hd, Wd, _ptr(dst), dst.strides[0],
+		int(interpolation)))
+	return dst[:, :, 0] if squeeze else dst
+
+
+def dewarp_u8(src, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
+	"""Fused grid_fill + remap_u8: the dense map never exists in memory."""
+	src, squeeze = _image(src)
+	nodes = _c(nodes, np.float32)
+	H, W, C = src.shape
+	h, w = nodes.shape[:2]
+	dst = np.empty((h * cell, w * cell, C), dtype=np.uint8)
+	check(load().ogd_dewarp_u8(
+		_ptr(src), H, W, C, src.strides[0], _ptr(nodes), h, w, int(cell), float(sx), float(sy),
+		_ptr(dst), dst.strides[0], int(interpolation)))
+	return dst[:, :, 0] if squeeze else dst
+
+
+# ---- K3 / K1b -------------------------------------------------------------------------------------
+
+class Triangulation:
+	"""Device-resident piecewise-linear interpolant over a host (Qhull) triangulation."""
+
+	def __init__(self, points, simplices, values, transform=None):
+		points = _c(points, np.float64)
+		simplices = _c(simplices, np.int32)
+		values = _c(values, np.float64)
+		if values.ndim == 1:
+			values = values[:, np.newaxis]
+		if transform is not None:
+			transform = _c(transform, np.float64)
+			if transform.shape != (len(simplices), 3, 2):
+				raise ValueError("transform must have shape (nt, 3, 2)")
+		if len(values) != len(points):
+			raise ValueError("one value row per point expected")
+		self.nv = values.shape[1]
+		self._h = c_void_p()
+		check(load().ogd_tri_create(
+			_ptr(points), len(points), _ptr(simplices), len(simplices),
+			_ptr(transform) if transform is not None else None, _ptr(values), self.nv,
+			ctypes.byref(self._h)))
+
+	@property
+	def handle(self):
+		return self._h
+
+	def close(self):
+		if self._h:
+			load().ogd_tri_destroy(self._h)
+			self._h = c_void_p()
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass
+
+
+def _bounds(bounds):
+	if bounds is None:
+		return None, None
+	b = np.array(bounds, dtype=np.float64).reshape(4)
+	return b, _ptr(b)
+
+
+def tri_eval(inner, extra, bounds, q):
+	q = _c(q, np.float64).reshape(-1, 2)
+	out = np.empty((len(q), extra.nv), dtype=np.float64)
+	b, bp = _bounds(bounds)
+	check(load().ogd_tri_eval(
+		inner.handle if inner is not None else None, extra.handle, bp, _ptr(q), len(q), _ptr(out)))
+	return out
+
+
+def tri_eval_ragged(inner, extra, bounds, q, offsets):
+	q = _c(q, np.float64).reshape(-1, 2)
+	offsets = _c(offsets, np.int64)
+	if len(offsets) < 1 or offsets[-1] != len(q):
+		raise ValueError("offsets must end at the number of points")
+	out = np.empty((len(q), extra.nv), dtype=np.float64)
+	b, bp = _bounds(bounds)
+	check(load().ogd_tri_eval_ragged(
+		inner.handle if inner is not None else None, extra.handle, bp, _ptr(q), _ptr(offsets),
+		len(offsets) - 1, _ptr(out)))
+	return out
+
+
+def tri_rasterize(inner, extra, bounds, x0, y0, step, nx, ny, order="xy", dtype=np.float64):
+	"""Values on the lattice (x0 + i*step, y0 + j*step); order "xy" -> (nx, ny, nv) like
+	lingrid's mgrid layout, "yx" -> (ny, nx, nv) image layout."""
+	nv = extra.nv
+	dtype = np.dtype(dtype)
+	if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+		raise TypeError("dtype must be float32 or float64")
+	if order == "xy":
+		out = np.empty((nx, ny, nv), dtype=dtype)
+		sx, sy = ny * nv, nv
+	elif order == "yx":
+		out = np.empty((ny, nx, nv), dtype=dtype)
+		sx, sy = nv, nx * nv
+	else:
+		raise ValueError(order)
+	b, bp = _bounds(bounds)
+	check(load().ogd_tri_rasterize(
+		inner.handle if inner is not None else None, extra.handle, bp, float(x0), float(y0),
+		float(step), int(nx), int(ny), _ptr(out), sx, sy, int(dtype == np.float64)))
+	return out

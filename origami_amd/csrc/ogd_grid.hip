@@ -1,0 +1,201 @@
+// K1a — dense sampling grid from the node grid (ref: origami/core/dewarp.py:514-526), its strided
+// sub-sampling (ref: dewarp.py:557-559) and the inverse point map (ref: dewarp.py:561-576).
+//
+// HBM-bound: 8 B written per dense pixel, 8 B read per node (nodes stay in L1/L2: 628 KB at
+// 323 x 243).  Each thread owns two adjacent columns and walks GF_ROWS rows, so the horizontal
+// taps are computed once per thread and the horizontally-lerped node rows are re-used for all dense
+// rows that fall into the same node cell; every store is a 16-byte float4 and a wavefront writes
+// 1 KiB of one dense row per instruction.
+#include "ogd_common.h"
+#include "ogd_resize_math.h"
+
+namespace ogd {
+
+constexpr int GF_THREADS = 256;
+constexpr int GF_ROWS = 16;
+
+struct __attribute__((aligned(8))) float4_a8 {
+  float x, y, z, w;
+};
+
+__global__ __launch_bounds__(GF_THREADS) void grid_fill_kernel(
+    const float2* __restrict__ nodes, int h, int w, double inv_s, float scx, float scy,
+    float2* __restrict__ out, int Hd, int Wd) {
+  const int X = (blockIdx.x * GF_THREADS + threadIdx.x) * 2;
+  if (X >= Wd) return;
+  const bool pair = (X + 1 < Wd);
+  const Tap tx0 = tap_x(X, inv_s, w);
+  const Tap tx1 = tap_x(pair ? X + 1 : X, inv_s, w);
+  const int Y0 = blockIdx.y * GF_ROWS;
+  const int Y1 = min(Y0 + GF_ROWS, Hd);
+
+  int cur0 = -1, cur1 = -1;
+  float2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f};  // horizontally lerped node row i0 for column X, X+1
+  float2 tb0 = {0.f, 0.f}, tb1 = {0.f, 0.f};  // same for node row i1
+  for (int Y = Y0; Y < Y1; ++Y) {
+    const Tap ty = tap_y(Y, inv_s, h);  // wave-uniform
+    if (ty.i0 != cur0 || ty.i1 != cur1) {
+      const float2* r0 = nodes + (size_t)ty.i0 * w;
+      const float2* r1 = nodes + (size_t)ty.i1 * w;
+      float2 a = r0[tx0.i0], b = r0[tx0.i1], c = r0[tx1.i0], d = r0[tx1.i1];
+      ta0 = make_float2(lerp2(a.x, tx0.w0, b.x, tx0.w1), lerp2(a.y, tx0.w0, b.y, tx0.w1));
+      ta1 = make_float2(lerp2(c.x, tx1.w0, d.x, tx1.w1), lerp2(c.y, tx1.w0, d.y, tx1.w1));
+      a = r1[tx0.i0], b = r1[tx0.i1], c = r1[tx1.i0], d = r1[tx1.i1];
+      tb0 = make_float2(lerp2(a.x, tx0.w0, b.x, tx0.w1), lerp2(a.y, tx0.w0, b.y, tx0.w1));
+      tb1 = make_float2(lerp2(c.x, tx1.w0, d.x, tx1.w1), lerp2(c.y, tx1.w0, d.y, tx1.w1));
+      cur0 = ty.i0;
+      cur1 = ty.i1;
+    }
+    float4_a8 v;
+    v.x = __fmul_rn(lerp2(ta0.x, ty.w0, tb0.x, ty.w1), scx);
+    v.y = __fmul_rn(lerp2(ta0.y, ty.w0, tb0.y, ty.w1), scy);
+    v.z = __fmul_rn(lerp2(ta1.x, ty.w0, tb1.x, ty.w1), scx);
+    v.w = __fmul_rn(lerp2(ta1.y, ty.w0, tb1.y, ty.w1), scy);
+    float2* o = out + (size_t)Y * Wd + X;
+    if (pair)
+      *reinterpret_cast<float4_a8*>(o) = v;
+    else
+      *o = make_float2(v.x, v.y);
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_points_strided_kernel(
+    const float2* __restrict__ nodes, int h, int w, double inv_s, int step, float2* __restrict__ out,
+    int oh, int ow) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  if (ox >= ow || oy >= oh) return;
+  const Tap tx = tap_x(ox * step, inv_s, w);
+  const Tap ty = tap_y(oy * step, inv_s, h);
+  out[(size_t)oy * ow + ox] = dense_at(nodes, w, tx, ty);
+}
+
+// Inverse point map: bilinear (fp64) sample of the dense grid at fractional (y, x), extrapolating
+// linearly from the edge cell.  Follows scipy RegularGridInterpolator over (arange(Hd), arange(Wd)):
+//   i = searchsorted(grid, x, 'left') - 1, clamped to [0, n-2]; t = (x - i) / 1
+//   value = sum over (i, j) in [(i0,j0), (i0,j1), (i1,j0), (i1,j1)] of v * ((1 * wy) * wx)
+__device__ __forceinline__ int rgi_index(double x, int n) {
+  int i = (int)ceil(x) - 1;  // searchsorted(left) on integers: #{k : k < x} - 1
+  if (!(x == x)) i = n - 1;  // NaN sorts last
+  i = max(i, 0);
+  i = min(i, n - 2);
+  return i;
+}
+
+__global__ __launch_bounds__(256) void grid_sample_bilinear_kernel(
+    const float2* __restrict__ nodes, int h, int w, int s, double inv_s, const double2* __restrict__ q_yx,
+    int64_t nq, double2* __restrict__ out_xy) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nq) return;
+  const int Hd = h * s, Wd = w * s;
+  const double y = q_yx[k].x, x = q_yx[k].y;
+  const int iy = rgi_index(y, Hd), ix = rgi_index(x, Wd);
+  const double ty = y - (double)iy, tx = x - (double)ix;
+  const Tap ax0 = tap_x(ix, inv_s, w), ax1 = tap_x(ix + 1, inv_s, w);
+  const Tap ay0 = tap_y(iy, inv_s, h), ay1 = tap_y(iy + 1, inv_s, h);
+  const float2 v00 = dense_at(nodes, w, ax0, ay0), v01 = dense_at(nodes, w, ax1, ay0);
+  const float2 v10 = dense_at(nodes, w, ax0, ay1), v11 = dense_at(nodes, w, ax1, ay1);
+  const double w00 = __dmul_rn(1.0 - ty, 1.0 - tx), w01 = __dmul_rn(1.0 - ty, tx);
+  const double w10 = __dmul_rn(ty, 1.0 - tx), w11 = __dmul_rn(ty, tx);
+  double ox = 0.0, oy = 0.0;
+  ox = __dadd_rn(ox, __dmul_rn((double)v00.x, w00));
+  oy = __dadd_rn(oy, __dmul_rn((double)v00.y, w00));
+  ox = __dadd_rn(ox, __dmul_rn((double)v01.x, w01));
+  oy = __dadd_rn(oy, __dmul_rn((double)v01.y, w01));
+  ox = __dadd_rn(ox, __dmul_rn((double)v10.x, w10));
+  oy = __dadd_rn(oy, __dmul_rn((double)v10.y, w10));
+  ox = __dadd_rn(ox, __dmul_rn((double)v11.x, w11));
+  oy = __dadd_rn(oy, __dmul_rn((double)v11.y, w11));
+  out_xy[k] = make_double2(ox, oy);
+}
+
+static int check_nodes(int h, int w, int s) {
+  OGD_REQUIRE(h >= 1 && w >= 1, "node grid must be at least 1x1 (got %dx%d)", h, w);
+  OGD_REQUIRE(s >= 1, "cell size must be >= 1 (got %d)", s);
+  OGD_REQUIRE((int64_t)h * s < INT_MAX && (int64_t)w * s < INT_MAX, "dense grid too large");
+  return OGD_OK;
+}
+
+}  // namespace ogd
+
+using namespace ogd;
+
+extern "C" {
+
+int ogd_grid_fill_dev(const float* d_nodes, int h, int w, int s, float sx, float sy, float* d_out,
+                      void* stream) {
+  OGD_TRY(check_nodes(h, w, s));
+  OGD_REQUIRE(d_nodes && d_out, "null pointer");
+  OGD_TRY(ensure_device());
+  const int Hd = h * s, Wd = w * s;
+  dim3 grid((Wd + 2 * GF_THREADS - 1) / (2 * GF_THREADS), (Hd + GF_ROWS - 1) / GF_ROWS);
+  OGD_REQUIRE(grid.y <= 65535u, "dense grid too tall");
+  hipLaunchKernelGGL(grid_fill_kernel, grid, dim3(GF_THREADS), 0, as_stream(stream),
+                     reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy,
+                     reinterpret_cast<float2*>(d_out), Hd, Wd);
+  return check_launch("grid_fill_kernel");
+}
+
+int ogd_grid_fill(const float* nodes, int h, int w, int s, float sx, float sy, float* out) {
+  OGD_TRY(check_nodes(h, w, s));
+  OGD_REQUIRE(nodes && out, "null pointer");
+  OGD_TRY(ensure_device());
+  const size_t nb = (size_t)h * w * 2 * sizeof(float);
+  const size_t ob = (size_t)h * s * (size_t)w * s * 2 * sizeof(float);
+  DevBuf dn, dout;
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(dout.alloc(ob));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_grid_fill_dev(dn.as<float>(), h, w, s, sx, sy, dout.as<float>(), nullptr));
+  OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_grid_points_strided(const float* nodes, int h, int w, int s, int step, float* out) {
+  OGD_TRY(check_nodes(h, w, s));
+  OGD_REQUIRE(nodes && out, "null pointer");
+  OGD_REQUIRE(step >= 1, "step must be >= 1");
+  OGD_TRY(ensure_device());
+  const int oh = (h * s + step - 1) / step, ow = (w * s + step - 1) / step;
+  OGD_REQUIRE(oh <= 65535, "too many output rows");
+  const size_t nb = (size_t)h * w * 2 * sizeof(float);
+  const size_t ob = (size_t)oh * ow * 2 * sizeof(float);
+  DevBuf dn, dout;
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(dout.alloc(ob));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  dim3 grid((ow + 255) / 256, oh);
+  hipLaunchKernelGGL(grid_points_strided_kernel, grid, dim3(256), 0, nullptr, dn.as<float2>(), h, w,
+                     1.0 / (double)s, step, dout.as<float2>(), oh, ow);
+  OGD_TRY(check_launch("grid_points_strided_kernel"));
+  OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_grid_sample_bilinear(const float* nodes, int h, int w, int s, const double* q_yx, int64_t nq,
+                             double* out_xy) {
+  OGD_TRY(check_nodes(h, w, s));
+  OGD_REQUIRE(nodes && (nq == 0 || (q_yx && out_xy)), "null pointer");
+  OGD_REQUIRE(nq >= 0, "negative point count");
+  OGD_REQUIRE((int64_t)h * s >= 2 && (int64_t)w * s >= 2, "dense grid must be at least 2x2");
+  if (nq == 0) return OGD_OK;
+  OGD_TRY(ensure_device());
+  const size_t nb = (size_t)h * w * 2 * sizeof(float);
+  const size_t qb = (size_t)nq * 2 * sizeof(double);
+  DevBuf dn, dq, dout;
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(dq.alloc(qb));
+  OGD_TRY(dout.alloc(qb));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(dq.p, q_yx, qb, hipMemcpyHostToDevice));
+  const int64_t nblk = (nq + 255) / 256;
+  OGD_REQUIRE(nblk < INT_MAX, "too many points");
+  hipLaunchKernelGGL(grid_sample_bilinear_kernel, dim3((unsigned)nblk), dim3(256), 0, nullptr,
+                     dn.as<float2>(), h, w, s, 1.0 / (double)s, dq.as<double2>(), nq,
+                     dout.as<double2>());
+  OGD_TRY(check_launch("grid_sample_bilinear_kernel"));
+  OGD_HIP(hipMemcpy(out_xy, dout.p, qb, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+}  // extern "C"

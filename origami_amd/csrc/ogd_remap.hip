@@ -1,0 +1,280 @@
+// K2 — remap of uint8 pages / label maps through the dense sampling grid, and the fused
+// grid-fill + remap.  ref: origami/core/dewarp.py:608-627 (cv2.remap, BORDER_CONSTANT 0).
+//
+// Arithmetic restated from OpenCV 4.2 imgproc remap (CV_32FC2 map, CV_8U source):
+//   linear : sx = cvRound(mx * 32), sy = cvRound(my * 32)        (fp32 product, round-half-even;
+//            out of int range / NaN -> INT_MIN as cvtss2si does)
+//            ix = sat_i16(sx >> 5), fx = sx & 31 (same for y)
+//            dst = (sum_ij w_ij * P(ix+i, iy+j) + 2^14) >> 15, w_ij = 32 * a_i * b_j,
+//            a = (32 - fx, fx), b = (32 - fy, fy); P = 0 outside the image.
+//            (all w_ij are multiples of 32, so this equals (sum a_i b_j P + 512) >> 10; the table
+//             entry fx = fy = 0 is stored as {32767, 0, 0, 1}, which gives the same byte.)
+//   nearest: ix = sat_i16(cvRound(mx)), iy likewise; dst = P(ix, iy).
+//
+// HBM traffic per output pixel: 8 B of map read + C B written + ~C B of source (each source byte is
+// read from HBM once; neighbouring taps hit L1/L2).  One thread owns 4 adjacent output pixels: the
+// map is read as two 16-byte loads, the result is written as one 4*C-byte store, and a wavefront
+// covers 256 pixels of one output row, so the source window it gathers from is a few cache lines.
+#include "ogd_common.h"
+#include "ogd_resize_math.h"
+
+namespace ogd {
+
+constexpr int RM_TX = 64;  // threads along x (one wavefront = one row segment)
+constexpr int RM_TY = 4;   // rows per block
+constexpr int RM_PX = 4;   // pixels per thread
+
+__device__ __forceinline__ int cv_round(float v) {
+  const float r = rintf(v);
+  return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : INT_MIN;
+}
+
+__device__ __forceinline__ int sat_i16(int v) { return min(max(v, -32768), 32767); }
+
+template <int C>
+__device__ __forceinline__ void sample_linear(const uint8_t* __restrict__ src, int H, int W,
+                                              ptrdiff_t ss, float mx, float my, uint8_t* o) {
+  const int sx = cv_round(__fmul_rn(mx, 32.f)), sy = cv_round(__fmul_rn(my, 32.f));
+  const int ix = sat_i16(sx >> 5), iy = sat_i16(sy >> 5);
+  const int a1 = sx & 31, b1 = sy & 31, a0 = 32 - a1, b0 = 32 - b1;
+  if ((unsigned)ix < (unsigned)max(W - 1, 0) && (unsigned)iy < (unsigned)max(H - 1, 0)) {
+    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int top = a0 * p[c] + a1 * p[C + c];
+      const int bot = a0 * p[ss + c] + a1 * p[ss + C + c];
+      o[c] = (uint8_t)((b0 * top + b1 * bot + 512) >> 10);
+    }
+  } else if (ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = 0;
+  } else {
+    const bool x0 = ix >= 0, x1 = ix + 1 < W, y0 = iy >= 0, y1 = iy + 1 < H;
+    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int v00 = (x0 && y0) ? p[c] : 0, v01 = (x1 && y0) ? p[C + c] : 0;
+      const int v10 = (x0 && y1) ? p[ss + c] : 0, v11 = (x1 && y1) ? p[ss + C + c] : 0;
+      o[c] = (uint8_t)((b0 * (a0 * v00 + a1 * v01) + b1 * (a0 * v10 + a1 * v11) + 512) >> 10);
+    }
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void sample_nearest(const uint8_t* __restrict__ src, int H, int W,
+                                               ptrdiff_t ss, float mx, float my, uint8_t* o) {
+  const int ix = sat_i16(cv_round(mx)), iy = sat_i16(cv_round(my));
+  if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
+    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = p[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = 0;
+  }
+}
+
+template <int C, int INTERP>
+__device__ __forceinline__ void sample(const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss,
+                                       float mx, float my, uint8_t* o) {
+  if (INTERP == OGD_INTER_LINEAR)
+    sample_linear<C>(src, H, W, ss, mx, my, o);
+  else
+    sample_nearest<C>(src, H, W, ss, mx, my, o);
+}
+
+template <int N>
+__device__ __forceinline__ void store_bytes(uint8_t* dst, const uint8_t* v) {
+  // N is a multiple of 4: dword stores at byte alignment (gfx950 runs in unaligned access mode)
+#pragma unroll
+  for (int k = 0; k < N; k += 4) {
+    uint32_t u = (uint32_t)v[k] | ((uint32_t)v[k + 1] << 8) | ((uint32_t)v[k + 2] << 16) |
+                 ((uint32_t)v[k + 3] << 24);
+    __builtin_memcpy(dst + k, &u, 4);
+  }
+}
+
+struct __attribute__((aligned(8))) map4 {
+  float v[8];
+};
+
+template <int C, int INTERP>
+__global__ __launch_bounds__(RM_TX* RM_TY) void remap_u8_kernel(
+    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float* __restrict__ map,
+    int Hd, int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds) {
+  const int X = (blockIdx.x * RM_TX + threadIdx.x) * RM_PX;
+  const int Y = blockIdx.y * RM_TY + threadIdx.y;
+  if (X >= Wd || Y >= Hd) return;
+  const float* m = map + ((size_t)Y * Wd + X) * 2;
+  uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
+  uint8_t o[RM_PX * C];
+  if (X + RM_PX <= Wd) {
+    const map4 mv = *reinterpret_cast<const map4*>(m);
+#pragma unroll
+    for (int k = 0; k < RM_PX; ++k)
+      sample<C, INTERP>(src, H, W, ss, mv.v[2 * k], mv.v[2 * k + 1], o + k * C);
+    store_bytes<RM_PX * C>(d, o);
+  } else {
+    for (int k = 0; X + k < Wd; ++k) {
+      sample<C, INTERP>(src, H, W, ss, m[2 * k], m[2 * k + 1], o);
+      for (int c = 0; c < C; ++c) d[k * C + c] = o[c];
+    }
+  }
+}
+
+// Fused variant: the map value of every output pixel is recomputed from the node grid (K1a
+// arithmetic, bit-identical to grid_fill_kernel) instead of being read from HBM.
+template <int C, int INTERP>
+__global__ __launch_bounds__(RM_TX* RM_TY) void dewarp_u8_kernel(
+    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float2* __restrict__ nodes,
+    int h, int w, double inv_s, float scx, float scy, int Hd, int Wd, uint8_t* __restrict__ dst,
+    ptrdiff_t ds) {
+  const int X = (blockIdx.x * RM_TX + threadIdx.x) * RM_PX;
+  const int Y = blockIdx.y * RM_TY + threadIdx.y;
+  if (X >= Wd || Y >= Hd) return;
+  const Tap ty = tap_y(Y, inv_s, h);
+  uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
+  uint8_t o[RM_PX * C];
+  const int n = min(RM_PX, Wd - X);
+#pragma unroll
+  for (int k = 0; k < RM_PX; ++k) {
+    if (k < n) {
+      const Tap tx = tap_x(X + k, inv_s, w);
+      const float2 v = dense_at(nodes, w, tx, ty);
+      sample<C, INTERP>(src, H, W, ss, __fmul_rn(v.x, scx), __fmul_rn(v.y, scy), o + k * C);
+    }
+  }
+  if (n == RM_PX) {
+    store_bytes<RM_PX * C>(d, o);
+  } else {
+    for (int k = 0; k < n * C; ++k) d[k] = o[k];
+  }
+}
+
+static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) {
+  OGD_REQUIRE(H >= 1 && W >= 1, "%s: empty image (%dx%d)", what, W, H);
+  OGD_REQUIRE(H < 32768 && W < 32768, "%s: %dx%d exceeds the int16 coordinate range of remap", what, W, H);
+  OGD_REQUIRE(C == 1 || C == 3 || C == 4, "%s: %d channels not supported (1, 3 or 4)", what, C);
+  OGD_REQUIRE(stride >= (ptrdiff_t)W * C, "%s: row stride %td < %d bytes", what, stride, W * C);
+  return OGD_OK;
+}
+
+template <int C>
+static void launch_remap(int interp, dim3 grid, dim3 block, hipStream_t st, const uint8_t* src, int H,
+                         int W, ptrdiff_t ss, const float* map, int Hd, int Wd, uint8_t* dst,
+                         ptrdiff_t ds) {
+  if (interp == OGD_INTER_LINEAR)
+    hipLaunchKernelGGL((remap_u8_kernel<C, OGD_INTER_LINEAR>), grid, block, 0, st, src, H, W, ss, map,
+                       Hd, Wd, dst, ds);
+  else
+    hipLaunchKernelGGL((remap_u8_kernel<C, OGD_INTER_NEAREST>), grid, block, 0, st, src, H, W, ss, map,
+                       Hd, Wd, dst, ds);
+}
+
+template <int C>
+static void launch_dewarp(int interp, dim3 grid, dim3 block, hipStream_t st, const uint8_t* src, int H,
+                          int W, ptrdiff_t ss, const float2* nodes, int h, int w, double inv_s,
+                          float scx, float scy, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
+  if (interp == OGD_INTER_LINEAR)
+    hipLaunchKernelGGL((dewarp_u8_kernel<C, OGD_INTER_LINEAR>), grid, block, 0, st, src, H, W, ss, nodes,
+                       h, w, inv_s, scx, scy, Hd, Wd, dst, ds);
+  else
+    hipLaunchKernelGGL((dewarp_u8_kernel<C, OGD_INTER_NEAREST>), grid, block, 0, st, src, H, W, ss,
+                       nodes, h, w, inv_s, scx, scy, Hd, Wd, dst, ds);
+}
+
+}  // namespace ogd
+
+using namespace ogd;
+
+extern "C" {
+
+int ogd_remap_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_stride,
+                     const float* d_map_xy, int Hd, int Wd, uint8_t* d_dst, ptrdiff_t dst_stride,
+                     int interp, void* stream) {
+  OGD_TRY(check_image(H, W, C, src_stride, "src"));
+  OGD_TRY(check_image(Hd, Wd, C, dst_stride, "dst"));
+  OGD_REQUIRE(d_src && d_map_xy && d_dst, "null pointer");
+  OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
+  OGD_TRY(ensure_device());
+  dim3 block(RM_TX, RM_TY);
+  dim3 grid((Wd + RM_TX * RM_PX - 1) / (RM_TX * RM_PX), (Hd + RM_TY - 1) / RM_TY);
+  hipStream_t st = as_stream(stream);
+  switch (C) {
+    case 1: launch_remap<1>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+    case 3: launch_remap<3>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+    default: launch_remap<4>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+  }
+  return check_launch("remap_u8_kernel");
+}
+
+int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_stride,
+                      const float* d_nodes, int h, int w, int s, float sx, float sy, uint8_t* d_dst,
+                      ptrdiff_t dst_stride, int interp, void* stream) {
+  OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
+  OGD_REQUIRE((int64_t)h * s < 32768 && (int64_t)w * s < 32768, "dense grid too large");
+  const int Hd = h * s, Wd = w * s;
+  OGD_TRY(check_image(H, W, C, src_stride, "src"));
+  OGD_TRY(check_image(Hd, Wd, C, dst_stride, "dst"));
+  OGD_REQUIRE(d_src && d_nodes && d_dst, "null pointer");
+  OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
+  OGD_TRY(ensure_device());
+  dim3 block(RM_TX, RM_TY);
+  dim3 grid((Wd + RM_TX * RM_PX - 1) / (RM_TX * RM_PX), (Hd + RM_TY - 1) / RM_TY);
+  hipStream_t st = as_stream(stream);
+  const float2* nodes = reinterpret_cast<const float2*>(d_nodes);
+  const double inv_s = 1.0 / (double)s;
+  switch (C) {
+    case 1: launch_dewarp<1>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
+    case 3: launch_dewarp<3>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
+    default: launch_dewarp<4>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
+  }
+  return check_launch("dewarp_u8_kernel");
+}
+
+int ogd_remap_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, const float* map_xy,
+                 int Hd, int Wd, uint8_t* dst, ptrdiff_t dst_stride, int interp) {
+  OGD_TRY(check_image(H, W, C, src_stride, "src"));
+  OGD_TRY(check_image(Hd, Wd, C, dst_stride, "dst"));
+  OGD_REQUIRE(src && map_xy && dst, "null pointer");
+  OGD_TRY(ensure_device());
+  const size_t sb = (size_t)src_stride * H, mb = (size_t)Hd * Wd * 2 * sizeof(float);
+  const size_t drow = (size_t)Wd * C;
+  DevBuf dsrc, dmap, ddst;
+  OGD_TRY(dsrc.alloc(sb));
+  OGD_TRY(dmap.alloc(mb));
+  OGD_TRY(ddst.alloc(drow * Hd));
+  // the last source row may be shorter than the stride in the caller's buffer
+  OGD_HIP(hipMemcpy2D(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(dmap.p, map_xy, mb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_remap_u8_dev(dsrc.as<uint8_t>(), H, W, C, src_stride, dmap.as<float>(), Hd, Wd,
+                           ddst.as<uint8_t>(), (ptrdiff_t)drow, interp, nullptr));
+  OGD_HIP(hipMemcpy2D(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_dewarp_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, const float* nodes,
+                  int h, int w, int s, float sx, float sy, uint8_t* dst, ptrdiff_t dst_stride,
+                  int interp) {
+  OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
+  OGD_REQUIRE((int64_t)h * s < 32768 && (int64_t)w * s < 32768, "dense grid too large");
+  const int Hd = h * s, Wd = w * s;
+  OGD_TRY(check_image(H, W, C, src_stride, "src"));
+  OGD_TRY(check_image(Hd, Wd, C, dst_stride, "dst"));
+  OGD_REQUIRE(src && nodes && dst, "null pointer");
+  OGD_TRY(ensure_device());
+  const size_t sb = (size_t)src_stride * H, nb = (size_t)h * w * 2 * sizeof(float);
+  const size_t drow = (size_t)Wd * C;
+  DevBuf dsrc, dn, ddst;
+  OGD_TRY(dsrc.alloc(sb));
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(ddst.alloc(drow * Hd));
+  OGD_HIP(hipMemcpy2D(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_dewarp_u8_dev(dsrc.as<uint8_t>(), H, W, C, src_stride, dn.as<float>(), h, w, s, sx, sy,
+                            ddst.as<uint8_t>(), (ptrdiff_t)drow, interp, nullptr));
+  OGD_HIP(hipMemcpy2D(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+}  // extern "C"

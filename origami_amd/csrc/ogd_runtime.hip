@@ -1,0 +1,125 @@
+// Library plumbing: error strings, lazy per-thread device binding, raw device-memory helpers.
+// No HIP call is made before the first entry point runs, so the library can be dlopen()ed before
+// origami's Pool forks its workers (ref: origami/batch/core/processor.py:483).
+#include "ogd_common.h"
+#include <cstring>
+#include <string>
+
+namespace ogd {
+
+static thread_local char g_err[512] = "";
+static thread_local int g_bound_device = -2;  // -2: not bound yet
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+static int bind_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(OGD_ERR_NODEVICE, "no HIP device visible (%s)",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0) {
+    const char* env = getenv("OGD_DEVICE");
+    device = env ? atoi(env) : -1;
+  }
+  if (device < 0) {
+    // keep whatever device the hosting process already selected (e.g. torch.cuda.set_device)
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= n) return fail(OGD_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  OGD_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  OGD_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(OGD_ERR_NODEVICE, "device %d is %s; this library carries gfx950 code only", device,
+                prop.gcnArchName);
+  g_bound_device = device;
+  return OGD_OK;
+}
+
+int ensure_device() {
+  if (g_bound_device >= 0) {
+    // the host may have switched devices on this thread since; re-assert ours
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == g_bound_device) return OGD_OK;
+    OGD_HIP(hipSetDevice(g_bound_device));
+    return OGD_OK;
+  }
+  return bind_device(-1);
+}
+
+}  // namespace ogd
+
+using namespace ogd;
+
+extern "C" {
+
+const char* ogd_last_error(void) { return g_err; }
+
+int ogd_version(void) { return 100; }
+
+int ogd_device_count(int* count) {
+  OGD_REQUIRE(count != nullptr, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(OGD_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return OGD_OK;
+}
+
+int ogd_init(int device) { return bind_device(device); }
+
+int ogd_dev_alloc(void** dptr, size_t bytes) {
+  OGD_REQUIRE(dptr != nullptr, "dptr is NULL");
+  OGD_TRY(ensure_device());
+  *dptr = nullptr;
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+  if (e != hipSuccess)
+    return fail(OGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return OGD_OK;
+}
+
+int ogd_dev_free(void* dptr) {
+  if (!dptr) return OGD_OK;
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipFree(dptr));
+  return OGD_OK;
+}
+
+int ogd_memcpy_h2d(void* dptr, const void* hptr, size_t bytes, void* stream) {
+  OGD_REQUIRE(dptr && hptr, "null pointer");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_memcpy_d2h(void* hptr, const void* dptr, size_t bytes, void* stream) {
+  OGD_REQUIRE(dptr && hptr, "null pointer");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_stream_sync(void* stream) {
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipStreamSynchronize(as_stream(stream)));
+  return OGD_OK;
+}
+
+}  // extern "C"

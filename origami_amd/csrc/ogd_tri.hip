@@ -1,0 +1,550 @@
+// K3 / K1b — piecewise-linear interpolation over a host-built Delaunay triangulation.
+// ref: origami/core/lingrid.py:174-189 (Interpolator.__call__: clip, inner, extra, NaN merge),
+//      :252-282 (dense lattice variant), :286-290 (scipy LinearNDInterpolator x2);
+//      origami/core/dewarp.py:158-161 (Transformer.__call__), origami/batch/detect/dewarp.py:26.
+//
+// Arithmetic follows scipy.interpolate.LinearNDInterpolator (interpnd / qhull.pyx), in fp64:
+//   c0 = T00*(x - r0) + T01*(y - r1);  c1 = T10*(x - r0) + T11*(y - r1);  c2 = (1 - c0) - c1
+//   inside  <=>  -eps <= c_j <= 1 + eps for all j,  eps = 100 * DBL_EPSILON
+//   value_k = ((c0 * v0k) + c1 * v1k) + c2 * v2k            (no FMA contraction)
+//   no containing simplex -> NaN.
+// T / r come from scipy's Delaunay.transform (the host "topology" stage); the point locator is a
+// uniform bucket grid over the triangulation's bounding box (CSR lists of the triangles that
+// overlap each cell, ascending index), so a query tests ~2-4 triangles and takes the first hit.
+// A point on a shared edge may resolve to a different neighbour than scipy's walk does; both give
+// the same value up to the last bits (the interpolant is continuous).
+//
+// Triangle record (fp64): {T00, T01, T10, T11, r0, r1, v0[nv], v1[nv], v2[nv]} = 72 B (nv=1), 96 B (nv=2).
+#include "ogd_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+struct ogd_tri {
+  int device = -1;
+  int nt = 0, nv = 0, rec = 0;  // rec = doubles per triangle record
+  double* d_rec = nullptr;      // [nt][rec]
+  int* d_cell_start = nullptr;  // [gnx*gny + 1]
+  int* d_cell_tris = nullptr;   // [cell_start[gnx*gny]]
+  int gnx = 1, gny = 1;
+  double gx0 = 0, gy0 = 0, inv_cw = 0, inv_ch = 0;
+  int max_cell = 0;  // longest cell list
+};
+
+namespace ogd {
+
+constexpr double TRI_EPS = 100.0 * 2.220446049250313e-16;
+
+struct TriView {
+  const double* rec;
+  const int* cell_start;
+  const int* cell_tris;
+  int nv, reclen, gnx, gny;
+  double gx0, gy0, inv_cw, inv_ch;
+};
+
+static TriView view_of(const ogd_tri* t) {
+  TriView v;
+  v.rec = t->d_rec;
+  v.cell_start = t->d_cell_start;
+  v.cell_tris = t->d_cell_tris;
+  v.nv = t->nv;
+  v.reclen = t->rec;
+  v.gnx = t->gnx;
+  v.gny = t->gny;
+  v.gx0 = t->gx0;
+  v.gy0 = t->gy0;
+  v.inv_cw = t->inv_cw;
+  v.inv_ch = t->inv_ch;
+  return v;
+}
+
+struct Bounds {
+  double minx, miny, maxx, maxy;
+  int clip;
+};
+
+__device__ __forceinline__ int cell_of(const TriView& t, double x, double y) {
+  // NaN coordinates land in cell 0 and match no triangle
+  int cx = (int)floor((x - t.gx0) * t.inv_cw);
+  int cy = (int)floor((y - t.gy0) * t.inv_ch);
+  cx = min(max(cx, 0), t.gnx - 1);
+  cy = min(max(cy, 0), t.gny - 1);
+  return cy * t.gnx + cx;
+}
+
+// Barycentric test of one record; on success writes nv values.
+template <int NV>
+__device__ __forceinline__ bool tri_try(const double* __restrict__ r, double x, double y, double* out) {
+  const double dx = x - r[4], dy = y - r[5];
+  const double c0 = __dadd_rn(__dmul_rn(r[0], dx), __dmul_rn(r[1], dy));
+  const double c1 = __dadd_rn(__dmul_rn(r[2], dx), __dmul_rn(r[3], dy));
+  const double c2 = (1.0 - c0) - c1;
+  const double lo = -TRI_EPS, hi = 1.0 + TRI_EPS;
+  if (!(c0 >= lo && c0 <= hi && c1 >= lo && c1 <= hi && c2 >= lo && c2 <= hi)) return false;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double v = __dmul_rn(c0, r[6 + k]);
+    v = __dadd_rn(v, __dmul_rn(c1, r[6 + NV + k]));
+    v = __dadd_rn(v, __dmul_rn(c2, r[6 + 2 * NV + k]));
+    out[k] = v;
+  }
+  return true;
+}
+
+template <int NV>
+__device__ __forceinline__ bool tri_locate(const TriView& t, double x, double y, double* out) {
+  const int c = cell_of(t, x, y);
+  const int b = t.cell_start[c], e = t.cell_start[c + 1];
+  for (int k = b; k < e; ++k) {
+    const double* r = t.rec + (size_t)t.cell_tris[k] * (6 + 3 * NV);
+    if (tri_try<NV>(r, x, y, out)) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ double clipd(double v, double lo, double hi) {
+  // numpy.clip = minimum(maximum(v, lo), hi); NaN propagates
+  if (v != v) return v;
+  return fmin(fmax(v, lo), hi);
+}
+
+template <int NV>
+__device__ __forceinline__ void eval_point(const TriView& inner, int has_inner, const TriView& extra,
+                                           const Bounds& b, double x, double y, double* out) {
+  if (b.clip) {
+    x = clipd(x, b.minx, b.maxx);
+    y = clipd(y, b.miny, b.maxy);
+  }
+  if (has_inner && tri_locate<NV>(inner, x, y, out)) return;
+  if (tri_locate<NV>(extra, x, y, out)) return;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[k] = nan;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void tri_eval_kernel(TriView inner, int has_inner, TriView extra,
+                                                       Bounds b, const double2* __restrict__ q,
+                                                       int64_t nq, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double v[NV];
+  const double2 p = q[i];
+  eval_point<NV>(inner, has_inner, extra, b, p.x, p.y, v);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[i * NV + k] = v[k];
+}
+
+// One wavefront per ring (polygon shell, hole or linestring); lanes stride over its vertices, so a
+// wave's queries are spatially coherent and share bucket cells / triangle records in L1.
+template <int NV>
+__global__ __launch_bounds__(256) void tri_eval_ragged_kernel(TriView inner, int has_inner,
+                                                              TriView extra, Bounds b,
+                                                              const double2* __restrict__ q,
+                                                              const int64_t* __restrict__ offsets,
+                                                              int nrings, double* __restrict__ out) {
+  const int ring = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (ring >= nrings) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t beg = offsets[ring], end = offsets[ring + 1];
+  for (int64_t i = beg + lane; i < end; i += 64) {
+    double v[NV];
+    const double2 p = q[i];
+    eval_point<NV>(inner, has_inner, extra, b, p.x, p.y, v);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[i * NV + k] = v[k];
+  }
+}
+
+// K1b — barycentric rasteriser on a lattice.  One block per RS_TW x RS_TH lattice tile.  The tile's
+// (clipped) extent selects a rectangle of bucket cells; for every such cell the block stages the
+// triangle records of the cell in LDS (chunks of RS_CHUNK), and the lattice points that fall into
+// that cell test the staged triangles in list order — the same order tri_locate uses, so the
+// rasteriser is bit-identical to point queries.  Points the inner triangulation leaves open take
+// a second pass over the extrapolation triangulation.
+constexpr int RS_TW = 32, RS_TH = 8, RS_CHUNK = 96;
+
+template <int NV>
+__device__ __forceinline__ void raster_pass(const TriView& t, double* lds, double x, double y,
+                                            bool& found, double* val, double tx0, double ty0,
+                                            double tx1, double ty1) {
+  constexpr int REC = 6 + 3 * NV;
+  const int tid = threadIdx.y * RS_TW + threadIdx.x;
+  const int own = cell_of(t, x, y);
+  // cell rectangle touched by this tile (block-uniform: derived from the tile corners)
+  const int c00 = cell_of(t, tx0, ty0), c11 = cell_of(t, tx1, ty1);
+  const int cx0 = c00 % t.gnx, cy0 = c00 / t.gnx, cx1 = c11 % t.gnx, cy1 = c11 / t.gnx;
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    for (int cx = cx0; cx <= cx1; ++cx) {
+      const int c = cy * t.gnx + cx;
+      const int b = t.cell_start[c], e = t.cell_start[c + 1];
+      for (int base = b; base < e; base += RS_CHUNK) {
+        const int n = min(RS_CHUNK, e - base);
+        __syncthreads();  // previous chunk fully consumed
+        for (int idx = tid; idx < n * REC; idx += RS_TW * RS_TH) {
+          const int k = idx / REC, f = idx - k * REC;
+          lds[idx] = t.rec[(size_t)t.cell_tris[base + k] * REC + f];
+        }
+        __syncthreads();
+        if (!found && own == c) {
+          for (int k = 0; k < n; ++k)
+            if (tri_try<NV>(lds + k * REC, x, y, val)) {
+              found = true;
+              break;
+            }
+        }
+      }
+    }
+  }
+}
+
+template <int NV, typename OutT>
+__global__ __launch_bounds__(RS_TW* RS_TH) void tri_rasterize_kernel(
+    TriView inner, int has_inner, TriView extra, Bounds b, double x0, double y0, double step, int nx,
+    int ny, OutT* __restrict__ out, int64_t stride_x, int64_t stride_y) {
+  __shared__ double lds[RS_CHUNK * (6 + 3 * NV)];
+  const int ix = blockIdx.x * RS_TW + threadIdx.x, iy = blockIdx.y * RS_TH + threadIdx.y;
+  const bool live = ix < nx && iy < ny;
+  // lattice coordinates: x0 + i*step is exact for the integer lattices the reference uses
+  double x = x0 + (double)min(ix, nx - 1) * step, y = y0 + (double)min(iy, ny - 1) * step;
+  const int ixl = min((int)(blockIdx.x * RS_TW + RS_TW - 1), nx - 1);
+  const int iyl = min((int)(blockIdx.y * RS_TH + RS_TH - 1), ny - 1);
+  double tx0 = x0 + (double)(blockIdx.x * RS_TW) * step, ty0 = y0 + (double)(blockIdx.y * RS_TH) * step;
+  double tx1 = x0 + (double)ixl * step, ty1 = y0 + (double)iyl * step;
+  if (step < 0) {
+    double t = tx0; tx0 = tx1; tx1 = t;
+    t = ty0; ty0 = ty1; ty1 = t;
+  }
+  if (b.clip) {
+    x = clipd(x, b.minx, b.maxx);
+    y = clipd(y, b.miny, b.maxy);
+    tx0 = clipd(tx0, b.minx, b.maxx);
+    tx1 = clipd(tx1, b.minx, b.maxx);
+    ty0 = clipd(ty0, b.miny, b.maxy);
+    ty1 = clipd(ty1, b.miny, b.maxy);
+  }
+  bool found = !live;
+  double val[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) val[k] = __longlong_as_double(0x7ff8000000000000LL);
+  if (has_inner) raster_pass<NV>(inner, lds, x, y, found, val, tx0, ty0, tx1, ty1);
+  if (__syncthreads_or(!found)) raster_pass<NV>(extra, lds, x, y, found, val, tx0, ty0, tx1, ty1);
+  if (live) {
+    OutT* o = out + (int64_t)ix * stride_x + (int64_t)iy * stride_y;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) o[k] = (OutT)val[k];
+  }
+}
+
+// ---- host: records + bucket grid ----------------------------------------------------------------
+
+static inline double edge_fn(double ax, double ay, double bx, double by, double px, double py) {
+  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+
+// true if the triangle cannot touch the axis-aligned rectangle [x0,x1] x [y0,y1]
+static bool tri_misses_rect(const double* X, const double* Y, double x0, double y0, double x1, double y1) {
+  const double area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+  const double sgn = area >= 0 ? 1.0 : -1.0;
+  for (int k = 0; k < 3; ++k) {
+    const int a = k, b = (k + 1) % 3;
+    const double e0 = sgn * edge_fn(X[a], Y[a], X[b], Y[b], x0, y0);
+    const double e1 = sgn * edge_fn(X[a], Y[a], X[b], Y[b], x1, y0);
+    const double e2 = sgn * edge_fn(X[a], Y[a], X[b], Y[b], x0, y1);
+    const double e3 = sgn * edge_fn(X[a], Y[a], X[b], Y[b], x1, y1);
+    if (e0 < 0 && e1 < 0 && e2 < 0 && e3 < 0) return true;
+  }
+  return false;
+}
+
+template <class T>
+static int upload(T** d, const std::vector<T>& v) {
+  *d = nullptr;
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  hipError_t e = hipMalloc((void**)d, bytes);
+  if (e != hipSuccess) return fail(OGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  if (!v.empty()) OGD_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return OGD_OK;
+}
+
+struct BindDevice {
+  int prev = -1;
+  bool ok = true;
+  explicit BindDevice(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~BindDevice() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static int check_pair(const ogd_tri* inner, const ogd_tri* extra) {
+  OGD_REQUIRE(extra != nullptr, "extra triangulation is NULL");
+  OGD_REQUIRE(inner == nullptr || inner->nv == extra->nv, "inner/extra value widths differ (%d vs %d)",
+              inner ? inner->nv : 0, extra->nv);
+  OGD_REQUIRE(inner == nullptr || inner->device == extra->device, "inner/extra live on different devices");
+  return OGD_OK;
+}
+
+static Bounds make_bounds(const double* bounds) {
+  Bounds b;
+  b.clip = bounds != nullptr;
+  b.minx = bounds ? bounds[0] : 0;
+  b.miny = bounds ? bounds[1] : 0;
+  b.maxx = bounds ? bounds[2] : 0;
+  b.maxy = bounds ? bounds[3] : 0;
+  return b;
+}
+
+}  // namespace ogd
+
+using namespace ogd;
+
+extern "C" {
+
+int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, const double* transform,
+                   const double* vals, int nv, ogd_tri** out) {
+  OGD_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  OGD_REQUIRE(pts && simplices && vals, "null pointer");
+  OGD_REQUIRE(n >= 3 && nt >= 1, "need at least 3 points and 1 simplex (got %d, %d)", n, nt);
+  OGD_REQUIRE(nv == 1 || nv == 2, "value width %d not supported (1 or 2)", nv);
+  for (int64_t k = 0; k < (int64_t)nt * 3; ++k)
+    OGD_REQUIRE(simplices[k] >= 0 && simplices[k] < n, "simplex vertex %d out of range", simplices[k]);
+  OGD_TRY(ensure_device());
+
+  const int rec = 6 + 3 * nv;
+  std::vector<double> recs((size_t)nt * rec);
+  std::vector<char> usable(nt, 1);
+  double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+  for (int i = 0; i < n; ++i) {
+    const double x = pts[2 * i], y = pts[2 * i + 1];
+    OGD_REQUIRE(std::isfinite(x) && std::isfinite(y), "point %d is not finite", i);
+    bx0 = std::min(bx0, x); bx1 = std::max(bx1, x);
+    by0 = std::min(by0, y); by1 = std::max(by1, y);
+  }
+  for (int t = 0; t < nt; ++t) {
+    const int32_t* s = simplices + 3 * (size_t)t;
+    double* r = recs.data() + (size_t)t * rec;
+    if (transform) {
+      const double* T = transform + 6 * (size_t)t;
+      for (int k = 0; k < 6; ++k) r[k] = T[k];
+    } else {
+      // edge matrix columns = v0 - v2, v1 - v2; r = v2  (scipy Delaunay.transform layout)
+      const double ax = pts[2 * s[0]] - pts[2 * s[2]], bx = pts[2 * s[1]] - pts[2 * s[2]];
+      const double ay = pts[2 * s[0] + 1] - pts[2 * s[2] + 1], by = pts[2 * s[1] + 1] - pts[2 * s[2] + 1];
+      const double det = ax * by - bx * ay;
+      r[0] = by / det; r[1] = -bx / det; r[2] = -ay / det; r[3] = ax / det;
+      r[4] = pts[2 * s[2]]; r[5] = pts[2 * s[2] + 1];
+    }
+    for (int k = 0; k < 6; ++k)
+      if (!std::isfinite(r[k])) usable[t] = 0;  // degenerate simplex: never contains a point
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < nv; ++k) r[6 + j * nv + k] = vals[(size_t)s[j] * nv + k];
+  }
+
+  // bucket grid: about one cell per triangle, aspect-matched, at most 2048 per side
+  const double ex = std::max(bx1 - bx0, 1e-300), ey = std::max(by1 - by0, 1e-300);
+  double fx = std::sqrt((double)nt * ex / ey), fy = std::sqrt((double)nt * ey / ex);
+  const int gnx = (int)std::min(2048.0, std::max(1.0, std::floor(fx)));
+  const int gny = (int)std::min(2048.0, std::max(1.0, std::floor(fy)));
+  const double cw = ex / gnx, ch = ey / gny;
+  const double mx = 1e-7 * cw, my = 1e-7 * ch;  // slack: float error in cell_of + the eps band
+  std::vector<int> count((size_t)gnx * gny + 1, 0);
+  auto for_cells = [&](int t, auto&& fn) {
+    const int32_t* s = simplices + 3 * (size_t)t;
+    const double X[3] = {pts[2 * s[0]], pts[2 * s[1]], pts[2 * s[2]]};
+    const double Y[3] = {pts[2 * s[0] + 1], pts[2 * s[1] + 1], pts[2 * s[2] + 1]};
+    const double tx0 = std::min({X[0], X[1], X[2]}) - mx, tx1 = std::max({X[0], X[1], X[2]}) + mx;
+    const double ty0 = std::min({Y[0], Y[1], Y[2]}) - my, ty1 = std::max({Y[0], Y[1], Y[2]}) + my;
+    const int cx0 = std::min(gnx - 1, std::max(0, (int)std::floor((tx0 - bx0) / cw)));
+    const int cx1 = std::min(gnx - 1, std::max(0, (int)std::floor((tx1 - bx0) / cw)));
+    const int cy0 = std::min(gny - 1, std::max(0, (int)std::floor((ty0 - by0) / ch)));
+    const int cy1 = std::min(gny - 1, std::max(0, (int)std::floor((ty1 - by0) / ch)));
+    for (int cy = cy0; cy <= cy1; ++cy)
+      for (int cx = cx0; cx <= cx1; ++cx) {
+        const double rx0 = bx0 + cx * cw - mx, rx1 = bx0 + (cx + 1) * cw + mx;
+        const double ry0 = by0 + cy * ch - my, ry1 = by0 + (cy + 1) * ch + my;
+        if ((cx1 > cx0 || cy1 > cy0) && tri_misses_rect(X, Y, rx0, ry0, rx1, ry1)) continue;
+        fn(cy * gnx + cx);
+      }
+  };
+  for (int t = 0; t < nt; ++t)
+    if (usable[t]) for_cells(t, [&](int c) { ++count[(size_t)c + 1]; });
+  int max_cell = 0;
+  for (size_t c = 0; c < (size_t)gnx * gny; ++c) {
+    max_cell = std::max(max_cell, count[c + 1]);
+    OGD_REQUIRE((int64_t)count[c] + count[c + 1] < INT_MAX, "bucket grid overflow");
+    count[c + 1] += count[c];
+  }
+  std::vector<int> cell_tris((size_t)count[(size_t)gnx * gny]);
+  std::vector<int> cursor(count.begin(), count.end() - 1);
+  for (int t = 0; t < nt; ++t)
+    if (usable[t]) for_cells(t, [&](int c) { cell_tris[(size_t)cursor[c]++] = t; });
+
+  ogd_tri* h = new (std::nothrow) ogd_tri();
+  if (!h) return fail(OGD_ERR_NOMEM, "out of host memory");
+  (void)hipGetDevice(&h->device);
+  h->nt = nt; h->nv = nv; h->rec = rec;
+  h->gnx = gnx; h->gny = gny; h->gx0 = bx0; h->gy0 = by0;
+  h->inv_cw = 1.0 / cw; h->inv_ch = 1.0 / ch; h->max_cell = max_cell;
+  int st = upload(&h->d_rec, recs);
+  if (st == OGD_OK) st = upload(&h->d_cell_start, count);
+  if (st == OGD_OK) st = upload(&h->d_cell_tris, cell_tris);
+  if (st != OGD_OK) {
+    ogd_tri_destroy(h);
+    return st;
+  }
+  *out = h;
+  return OGD_OK;
+}
+
+int ogd_tri_destroy(ogd_tri* t) {
+  if (!t) return OGD_OK;
+  {
+    BindDevice bind(t->device);
+    if (t->d_rec) (void)hipFree(t->d_rec);
+    if (t->d_cell_start) (void)hipFree(t->d_cell_start);
+    if (t->d_cell_tris) (void)hipFree(t->d_cell_tris);
+  }
+  delete t;
+  return OGD_OK;
+}
+
+int ogd_tri_eval_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds, const double* d_q,
+                     int64_t nq, double* d_out, void* stream) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nq >= 0, "negative point count");
+  if (nq == 0) return OGD_OK;
+  OGD_REQUIRE(d_q && d_out, "null pointer");
+  OGD_TRY(ensure_device());
+  const int64_t nblk = (nq + 255) / 256;
+  OGD_REQUIRE(nblk < INT_MAX, "too many points");
+  const TriView ve = view_of(extra), vi = inner ? view_of(inner) : ve;
+  const Bounds b = make_bounds(bounds);
+  const double2* q = reinterpret_cast<const double2*>(d_q);
+  if (extra->nv == 1)
+    hipLaunchKernelGGL(tri_eval_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vi,
+                       inner != nullptr, ve, b, q, nq, d_out);
+  else
+    hipLaunchKernelGGL(tri_eval_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vi,
+                       inner != nullptr, ve, b, q, nq, d_out);
+  return check_launch("tri_eval_kernel");
+}
+
+int ogd_tri_eval(const ogd_tri* inner, const ogd_tri* extra, const double* bounds, const double* q,
+                 int64_t nq, double* out) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nq >= 0, "negative point count");
+  if (nq == 0) return OGD_OK;
+  OGD_REQUIRE(q && out, "null pointer");
+  OGD_TRY(ensure_device());
+  const size_t qb = (size_t)nq * 2 * sizeof(double), ob = (size_t)nq * extra->nv * sizeof(double);
+  DevBuf dq, dout;
+  OGD_TRY(dq.alloc(qb));
+  OGD_TRY(dout.alloc(ob));
+  OGD_HIP(hipMemcpy(dq.p, q, qb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_tri_eval_dev(inner, extra, bounds, dq.as<double>(), nq, dout.as<double>(), nullptr));
+  OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_tri_eval_ragged_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
+                            const double* d_q, const int64_t* d_offsets, int nrings, double* d_out,
+                            void* stream) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nrings >= 0, "negative ring count");
+  if (nrings == 0) return OGD_OK;
+  OGD_REQUIRE(d_q && d_offsets && d_out, "null pointer");
+  OGD_TRY(ensure_device());
+  const TriView ve = view_of(extra), vi = inner ? view_of(inner) : ve;
+  const Bounds b = make_bounds(bounds);
+  const double2* q = reinterpret_cast<const double2*>(d_q);
+  const unsigned nblk = (unsigned)((nrings + 3) / 4);
+  if (extra->nv == 1)
+    hipLaunchKernelGGL(tri_eval_ragged_kernel<1>, dim3(nblk), dim3(256), 0, as_stream(stream), vi,
+                       inner != nullptr, ve, b, q, d_offsets, nrings, d_out);
+  else
+    hipLaunchKernelGGL(tri_eval_ragged_kernel<2>, dim3(nblk), dim3(256), 0, as_stream(stream), vi,
+                       inner != nullptr, ve, b, q, d_offsets, nrings, d_out);
+  return check_launch("tri_eval_ragged_kernel");
+}
+
+int ogd_tri_eval_ragged(const ogd_tri* inner, const ogd_tri* extra, const double* bounds, const double* q,
+                        const int64_t* offsets, int nrings, double* out) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nrings >= 0, "negative ring count");
+  if (nrings == 0) return OGD_OK;
+  OGD_REQUIRE(q && offsets && out, "null pointer");
+  OGD_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+  for (int r = 0; r < nrings; ++r)
+    OGD_REQUIRE(offsets[r + 1] >= offsets[r], "offsets must be non-decreasing (ring %d)", r);
+  const int64_t nq = offsets[nrings];
+  if (nq == 0) return OGD_OK;
+  OGD_TRY(ensure_device());
+  const size_t qb = (size_t)nq * 2 * sizeof(double), ob = (size_t)nq * extra->nv * sizeof(double);
+  const size_t fb = (size_t)(nrings + 1) * sizeof(int64_t);
+  DevBuf dq, dout, doff;
+  OGD_TRY(dq.alloc(qb));
+  OGD_TRY(dout.alloc(ob));
+  OGD_TRY(doff.alloc(fb));
+  OGD_HIP(hipMemcpy(dq.p, q, qb, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(doff.p, offsets, fb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_tri_eval_ragged_dev(inner, extra, bounds, dq.as<double>(), doff.as<int64_t>(), nrings,
+                                  dout.as<double>(), nullptr));
+  OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_tri_rasterize_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds, double x0,
+                          double y0, double step, int nx, int ny, void* d_out, int64_t stride_x,
+                          int64_t stride_y, int out_f64, void* stream) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nx >= 1 && ny >= 1, "empty lattice %dx%d", nx, ny);
+  OGD_REQUIRE(std::isfinite(x0) && std::isfinite(y0) && std::isfinite(step), "lattice is not finite");
+  OGD_REQUIRE(d_out != nullptr, "null pointer");
+  OGD_TRY(ensure_device());
+  dim3 block(RS_TW, RS_TH), grid((nx + RS_TW - 1) / RS_TW, (ny + RS_TH - 1) / RS_TH);
+  OGD_REQUIRE(grid.y <= 65535u, "lattice too tall");
+  const TriView ve = view_of(extra), vi = inner ? view_of(inner) : ve;
+  const Bounds b = make_bounds(bounds);
+  const int hi = inner != nullptr;
+  hipStream_t st = as_stream(stream);
+#define OGD_RASTER(NV, T)                                                                              \
+  hipLaunchKernelGGL((tri_rasterize_kernel<NV, T>), grid, block, 0, st, vi, hi, ve, b, x0, y0, step, nx, \
+                     ny, reinterpret_cast<T*>(d_out), stride_x, stride_y)
+  if (extra->nv == 1) {
+    if (out_f64) OGD_RASTER(1, double); else OGD_RASTER(1, float);
+  } else {
+    if (out_f64) OGD_RASTER(2, double); else OGD_RASTER(2, float);
+  }
+#undef OGD_RASTER
+  return check_launch("tri_rasterize_kernel");
+}
+
+int ogd_tri_rasterize(const ogd_tri* inner, const ogd_tri* extra, const double* bounds, double x0, double y0,
+                      double step, int nx, int ny, void* out, int64_t stride_x, int64_t stride_y,
+                      int out_f64) {
+  OGD_TRY(check_pair(inner, extra));
+  OGD_REQUIRE(nx >= 1 && ny >= 1, "empty lattice %dx%d", nx, ny);
+  OGD_REQUIRE(out != nullptr, "null pointer");
+  const int nv = extra->nv;
+  // host form: the output must be one dense block in either (x, y, k) or (y, x, k) order
+  const bool xy = stride_y == nv && stride_x == (int64_t)ny * nv;
+  const bool yx = stride_x == nv && stride_y == (int64_t)nx * nv;
+  OGD_REQUIRE(xy || yx, "host output must be dense [nx][ny][nv] or [ny][nx][nv]");
+  OGD_TRY(ensure_device());
+  const size_t ob = (size_t)nx * ny * nv * (out_f64 ? sizeof(double) : sizeof(float));
+  DevBuf dout;
+  OGD_TRY(dout.alloc(ob));
+  OGD_TRY(ogd_tri_rasterize_dev(inner, extra, bounds, x0, y0, step, nx, ny, dout.p, stride_x, stride_y,
+                                out_f64, nullptr));
+  OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+}  // extern "C"

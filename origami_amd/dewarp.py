@@ -1,0 +1,485 @@
+"""Dewarping with a vector field interpolated from scattered flow samples — the MI355X build of
+origami/core/dewarp.py (same classes, arguments, artifacts and errors).
+
+Host side (this file) keeps what is small and sequential: sample I/O, the Euler march of the node
+grid and its row intersections, artifact I/O.  Everything per pixel or per point runs in
+libogdewarp.so on the GPU:
+
+  Field.get / Transformer.__call__   -> K3  ogd_tri_eval[_ragged]   (ref: dewarp.py:119, 159)
+  Grid.points("full")                -> K1a ogd_grid_fill           (ref: dewarp.py:522-523)
+  Dewarper.dewarped / dewarp_image   -> K2  ogd_dewarp_u8 (fused K1a+K2; ref: dewarp.py:612-614, 625-627)
+  Grid.inverse                       -> ogd_grid_sample_bilinear    (ref: dewarp.py:565-567)
+"""
+
+import io
+import json
+import math
+import zipfile
+
+import numpy as np
+import PIL.Image
+
+from . import _shim
+from ._shim import INTER_LINEAR, INTER_NEAREST  # noqa: F401  (cv2-compatible constants)
+from .lingrid import lininterp
+
+
+class Geometry:
+	"""ref: origami/core/math.py:69-91."""
+
+	def __init__(self, w, h):
+		self._size = (w, h)
+
+	@property
+	def size(self):
+		return self._size
+
+	@property
+	def area(self):
+		w, h = self.size
+		return w * h
+
+	@property
+	def diameter(self):
+		w, h = self.size
+		return np.sqrt(w * w + h * h)
+
+	def rel_length(self, x):
+		return self.diameter * x
+
+	def rel_area(self, a):
+		return (self.diameter * a) ** 2
+
+
+class Samples:
+	"""Flow samples (x, y, phi) of one direction; `flow.zip` members <name>.npy / <name>.json
+	(ref: dewarp.py:34-105, docs/formats.md:145-187)."""
+
+	def __init__(self, geometry):
+		self._points = []
+		self._values = []
+		self._geometry = geometry
+
+	def __len__(self):
+		return len(self._points)
+
+	@staticmethod
+	def open(zf, name):
+		info = json.loads(zf.read("%s.json" % name))
+		array = np.load(io.BytesIO(zf.read("%s.npy" % name)), allow_pickle=False)
+		samples = Samples(Geometry(*info["size"]))
+		if array.size > 0:
+			samples._points = list(array[:, :2])
+			samples._values = list(array[:, 2])
+		else:
+			samples._points = np.empty((2, 0))
+			samples._values = []
+		return samples
+
+	def save(self, zf, name):
+		points = np.array(self._points)
+		values = np.array(self._values)
+		if points.size == 0:
+			array = np.empty((3, 0))
+		else:
+			array = np.hstack([points, values[:, np.newaxis]])
+		data = io.BytesIO()
+		np.save(data, array.astype(np.float64), allow_pickle=False)
+		zf.writestr("%s.npy" % name, data.getvalue())
+		zf.writestr("%s.json" % name, json.dumps(dict(version=1, size=self._geometry.size)))
+
+	@property
+	def geometry(self):
+		return self._geometry
+
+	@property
+	def points(self):
+		return self._points
+
+	@property
+	def values(self):
+		return self._values
+
+	def append(self, point, value):
+		self._points.append(point)
+		self._values.append(value)
+
+	def extend(self, points, values):
+		self._points.extend(points)
+		self._values.extend(values)
+
+	@property
+	def std(self):
+		return np.std(self._values) if len(self._values) > 3 else 0
+
+
+class Field:
+	"""Angle field -> unit direction field (ref: dewarp.py:108-140)."""
+
+	def __init__(self, samples, size, phi0):
+		self._size = size
+		if len(samples.points) <= 2:
+			self._interp = lambda pts: [phi0 for _ in pts]
+		else:
+			self._interp = lininterp(samples.points, samples.values, (0, 0, size[0], size[1]))
+
+	def get(self, pts):
+		angles = self._interp(pts)  # fp64 on the GPU
+		dx = np.cos(angles, dtype=np.float32)
+		dy = np.sin(angles, dtype=np.float32)
+		return np.squeeze(np.dstack([dx, dy]), axis=0)
+
+	def estimate_extent(self, axis, limit, step_size):
+		starts = range(0, self._size[1 - axis], step_size)
+		pts = np.zeros((len(starts), 2), dtype=np.float32)
+		pts[:, 1 - axis] = starts
+		n_steps = 1
+		max_steps = 2 * (1 + self._size[axis])
+		while np.any(pts[:, axis] < limit) and n_steps < max_steps:
+			pts += self.get(pts) * step_size
+			n_steps += 1
+		if n_steps >= max_steps:
+			raise RuntimeError("n_steps exceeded %d" % max_steps)
+		return n_steps
+
+
+class Transformer:
+	"""Forward point map warped page -> dewarped page (ref: dewarp.py:143-161)."""
+
+	def __init__(self, grid, grid_res):
+		h, w = grid.shape[:2]
+		source = grid.reshape((h * w, 2))
+		gy, gx = np.mgrid[0:h, 0:w]
+		target = np.stack([gx, gy], axis=-1).reshape((h * w, 2)) * grid_res
+		bounds = (
+			np.min(source[:, 0]), np.min(source[:, 1]),
+			np.max(source[:, 0]), np.max(source[:, 1]))
+		self._interp = lininterp(source, target, bounds)
+
+	def __call__(self, x, y):
+		pts = self._interp(np.squeeze(np.dstack([x, y]), axis=0))
+		assert not np.any(np.isnan(pts))
+		return pts[:, 0], pts[:, 1]
+
+	def transform_rings(self, rings):
+		"""All rings of a page in ONE launch, one wavefront per ring (K3 ragged); equivalent to
+		calling the transformer once per ring as shapely.ops.transform does
+		(ref: origami/batch/detect/dewarp.py:26)."""
+		if not rings:
+			return []
+		offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+		np.cumsum([len(r) for r in rings], out=offsets[1:])
+		flat = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings])
+		out = self._interp.ragged(flat, offsets)
+		assert not np.any(np.isnan(out))
+		return [out[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+
+
+def extrapolate(a, b, x):
+	v = b - a
+	v /= np.linalg.norm(v)
+	return b + x * v
+
+
+def make_slices(n, k):
+	s = math.ceil(n / k)
+	for i in range(0, n, s):
+		yield slice(i, i + s)
+
+
+class BatchIntersections:
+	"""Nearest crossing of each marching ray with the next grid row, all rays of a row at once
+	(ref: dewarp.py:176-263, ShapelyBatchIntersections).  Closed-form segment/segment
+	intersections in fp64 replace the shapely STRtree queries."""
+
+	def __init__(self, grid_h, grid_res, k=3):
+		self.grid_h = grid_h
+		self.grid_res = grid_res
+		# The reference builds its per-row pieces from numpy views, which pushes the first and the
+		# last node of rows 1.. of grid_h `large` pixels outwards IN PLACE — the last node once per
+		# piece that reaches the row end (ref: dewarp.py:199-212).  Reproduced, since the step
+		# length below is derived from the modified rows.
+		grid_w = grid_h.shape[1]
+		large = grid_w * grid_res
+		n_tail = sum(1 for i in range(0, grid_w, k - 1) if i != 0 and i + k >= grid_w)
+		for gy in range(1, grid_h.shape[0]):
+			row = grid_h[gy]
+			row[0] = extrapolate(row[1], row[0], large)
+			for _ in range(n_tail):
+				row[-1] = extrapolate(row[-2], row[-1], large)
+		self._rows = grid_h.astype(np.float64)
+
+	def _hits(self, p0, p1, row):
+		# (n rays) x (m segments) parametric solve; closed intervals, parallel pairs skipped
+		r = (p1 - p0)[:, np.newaxis, :]
+		a = row[np.newaxis, :-1, :]
+		s = row[np.newaxis, 1:, :] - a
+		q = a - p0[:, np.newaxis, :]
+		den = r[..., 0] * s[..., 1] - r[..., 1] * s[..., 0]
+		with np.errstate(divide="ignore", invalid="ignore"):
+			t = (q[..., 0] * s[..., 1] - q[..., 1] * s[..., 0]) / den
+			u = (q[..., 0] * r[..., 1] - q[..., 1] * r[..., 0]) / den
+		ok = (den != 0) & (t >= 0) & (t <= 1) & (u >= 0) & (u <= 1)
+		x = p0[:, np.newaxis, 0] + t * r[..., 0]
+		y = p0[:, np.newaxis, 1] + t * r[..., 1]
+		return ok, x, y
+
+	def __call__(self, pts0, pts1, gy):
+		n_rows = self.grid_h.shape[0] - 1
+		p0 = pts0.astype(np.float64)
+		p1 = pts1.astype(np.float64)
+		todo = np.arange(len(pts0))
+		dy = 0
+		while len(todo):
+			ok, x, y = self._hits(p0[todo], p1[todo], self._rows[gy + 1 + dy])
+			dist = np.sqrt((x - p0[todo, np.newaxis, 0]) ** 2 + (y - p0[todo, np.newaxis, 1]) ** 2)
+			dist[~ok] = np.inf
+			best = np.argmin(dist, axis=1)
+			found = ok[np.arange(len(todo)), best]
+			sel = todo[found]
+			pts1[sel, 0] = x[found, best[found]]
+			pts1[sel, 1] = y[found, best[found]]
+			todo = todo[~found]
+			if len(todo):
+				if gy + dy + 1 < n_rows:
+					dy += 1
+				else:
+					i = int(todo[0])
+					raise RuntimeError("failed to find intersection for i=%d, n=%d, %s to %s." % (
+						i, len(pts0), pts0[i], pts1[i]))
+
+
+class GridFactory:
+	"""ref: dewarp.py:292-493."""
+
+	def __init__(self, page, samples_h, samples_v, grid_res=25, max_grid_size=1000, num_threads=2):
+		size = page.warped.size
+		self._width = size[0]
+		self._height = size[1]
+		self._grid_res = grid_res
+		self._max_grid_size = max_grid_size
+		self._num_threads = num_threads
+		self._samples_h = samples_h
+		self._samples_v = samples_v
+		self._cache = {}
+
+	def _cached(self, key, make):
+		if key not in self._cache:
+			self._cache[key] = make()
+		return self._cache[key]
+
+	@property
+	def res(self):
+		return self._grid_res
+
+	@property
+	def field_h(self):
+		return self._cached("field_h", lambda: Field(
+			self._samples_h, (self._width, self._height), phi0=0))
+
+	@property
+	def field_v(self):
+		return self._cached("field_v", lambda: Field(
+			self._samples_v, (self._width, self._height), phi0=math.pi / 2))
+
+	@property
+	def grid_shape(self):
+		def make():
+			est_width = self.field_h.estimate_extent(0, self._width, step_size=self._grid_res)
+			est_height = self.field_v.estimate_extent(1, self._height, step_size=self._grid_res)
+			if max(est_width, est_height) > self._max_grid_size:
+				raise RuntimeError("estimated grid too big: (%d, %d)" % (est_height, est_width))
+			return est_height, est_width
+		return self._cached("grid_shape", make)
+
+	def _extend(self, grid_hv, axis, sign):
+		"""Append whole columns (axis 1) / rows (axis 0) by Euler steps of +-grid_res until every
+		border node lies outside the page (ref: dewarp.py:341-419)."""
+		field = (self.field_h if axis == 1 else self.field_v).get
+		limit = self._width if axis == 1 else self._height
+		edge = -1 if sign > 0 else 0
+		max_borders = self._max_grid_size // 2
+		pts = np.take(grid_hv, edge, axis=axis)
+		added = []
+
+		def inside(p):
+			c = p[:, 1 - axis]
+			return np.any(c < limit) if sign > 0 else np.any(c > 0)
+
+		while inside(pts):
+			if len(added) + 1 >= max_borders:
+				raise RuntimeError("border extension not terminating")
+			pts = pts + field(pts) * (self._grid_res * sign)
+			added.append(np.expand_dims(pts, axis))
+		if not added:
+			return grid_hv
+		parts = [grid_hv] + added if sign > 0 else added[::-1] + [grid_hv]
+		return np.concatenate(parts, axis=axis)
+
+	def extend_border_h(self, grid_hv, side):
+		if side not in ("left", "right"):
+			raise ValueError(side)
+		return self._extend(grid_hv, 1, -1 if side == "left" else 1)
+
+	def extend_border_v(self, grid_hv, side):
+		if side not in ("top", "bottom"):
+			raise ValueError(side)
+		return self._extend(grid_hv, 0, -1 if side == "top" else 1)
+
+	@property
+	def grid_h(self):
+		def make():
+			n_rows, n_cols = self.grid_shape
+			grid = np.zeros((n_rows, n_cols, 2), dtype=np.float32)
+			pts = np.zeros((n_rows, 2), dtype=np.float32)
+			pts[:, 1] = np.arange(n_rows) * self._grid_res
+			for gx in range(n_cols):
+				grid[:, gx, :] = pts
+				pts += self.field_h.get(pts) * self._grid_res
+			assert not np.any(np.isnan(grid))
+			return grid
+		return self._cached("grid_h", make)
+
+	@property
+	def grid_hv(self):
+		return self._cached("grid_hv", self._make_grid_hv)
+
+	def _make_grid_hv(self):
+		grid_h = self.grid_h
+		field_v = self.field_v.get
+		grid_hv = np.zeros(grid_h.shape, dtype=np.float32)
+		intersections = BatchIntersections(grid_h, self._grid_res)
+
+		def compute_slice(sel):
+			rise = np.max(grid_h[1:, sel, 1], axis=1) - np.min(grid_h[:-1, sel, 1], axis=1)
+			max_dy = max(0, np.max(rise)) if len(rise) else 0
+			max_step_len = max_dy / math.cos(60 * (math.pi / 180))
+			pts0 = grid_h[0][sel]
+			for gy in range(grid_h.shape[0] - 1):
+				grid_hv[gy, sel, :] = pts0
+				pts1 = pts0 + field_v(pts0) * max_step_len
+				intersections(pts0, pts1, gy)
+				pts0 = pts1
+			grid_hv[-1, sel, :] = pts0
+
+		if self._num_threads < 2:
+			compute_slice(slice(0, grid_h.shape[1]))
+		else:
+			# the reference maps these column slices over a 2-thread pool (dewarp.py:474-483); they
+			# are independent, and sequential order keeps the single GPU stream busy without races
+			for sel in make_slices(grid_h.shape[1], self._num_threads):
+				compute_slice(sel)
+
+		grid_hv = self.extend_border_h(grid_hv, "left")
+		grid_hv = self.extend_border_h(grid_hv, "right")
+		grid_hv = self.extend_border_v(grid_hv, "top")
+		grid_hv = self.extend_border_v(grid_hv, "bottom")
+		assert not np.any(np.isnan(grid_hv))
+		return grid_hv
+
+
+class Grid:
+	"""The marched node grid and everything derived from it (ref: dewarp.py:496-576)."""
+
+	def __init__(self, hv, res):
+		self._grid_hv = hv
+		self._grid_res = res
+		self._full = {}
+		self._transformer = None
+
+	@property
+	def geometry(self):
+		h, w = self._grid_hv.shape[:2]
+		r = self._grid_res
+		return Geometry(w * r, h * r)
+
+	def points(self, resolution="full", interpolation=INTER_LINEAR):
+		if resolution == "sample":
+			return self._grid_hv
+		elif resolution == "full":
+			if interpolation != INTER_LINEAR:
+				raise ValueError("only INTER_LINEAR dense grids are built on the GPU")
+			if "full" not in self._full:  # one array object per grid, like the reference's lru_cache
+				self._full["full"] = _shim.grid_fill(self._grid_hv, self._grid_res)
+			return self._full["full"]
+		else:
+			raise ValueError(resolution)
+
+	@property
+	def resolution(self):
+		return self._grid_res
+
+	@staticmethod
+	def create(*args, **kwargs):
+		factory = GridFactory(*args, **kwargs)
+		return Grid(factory.grid_hv, factory.res)
+
+	@staticmethod
+	def open(path):
+		with zipfile.ZipFile(path, "r") as zf:
+			info = json.loads(zf.read("meta.json").decode("utf8"))
+			grid = np.load(io.BytesIO(zf.read("data.npy")), allow_pickle=False)
+		return Grid(grid.reshape(info["shape"]), info["cell"])
+
+	def save(self, path, compression=zipfile.ZIP_DEFLATED):
+		data = io.BytesIO()
+		np.save(data, self._grid_hv.astype(np.float32), allow_pickle=False)
+		info = dict(version=1, cell=self._grid_res, shape=self._grid_hv.shape)
+		with zipfile.ZipFile(path, "w", compression) as zf:
+			zf.writestr("data.npy", data.getvalue())
+			zf.writestr("meta.json", json.dumps(info))
+
+	@property
+	def transformer(self):
+		if self._transformer is None:
+			r = self._grid_res
+			# points("full")[::r, ::r] evaluated directly at those pixels (ref: dewarp.py:557-559)
+			source = _shim.grid_points_strided(self._grid_hv, r, r)
+			self._transformer = Transformer(source, r)
+		return self._transformer
+
+	@property
+	def inverse_yx(self):
+		def f(pts_yx):
+			return _shim.grid_sample_bilinear(self._grid_hv, self._grid_res, pts_yx)
+		return f
+
+	@property
+	def inverse(self):
+		interp = self.inverse_yx
+
+		def f(pts):
+			return interp(np.flip(pts, axis=-1))
+		return f
+
+
+class Dewarper:
+	"""ref: dewarp.py:579-627."""
+
+	def __init__(self, im, grid):
+		self._im = im
+		self._grid = grid
+		self._dewarped = None
+
+	@property
+	def grid(self):
+		return self._grid
+
+	@property
+	def dewarped(self):
+		if self._dewarped is None:
+			self._dewarped = PIL.Image.fromarray(_shim.dewarp_u8(
+				np.array(self._im), self._grid.points("sample"), self._grid.resolution,
+				interpolation=INTER_LINEAR))
+		return self._dewarped
+
+	def dewarp_image(self, im, interpolation=INTER_LINEAR):
+		"""Remap an image of any size (label map, RGB page) through the page's grid, scaled by
+		the size ratio.  The reference multiplies its cached dense grid in place (dewarp.py:621-623),
+		which leaks the scale into later users; here the scale is applied to a private copy inside
+		the kernel, i.e. the behaviour of the reference's first call."""
+		w0, h0 = self._im.size
+		w1, h1 = im.size
+		return PIL.Image.fromarray(_shim.dewarp_u8(
+			np.array(im), self._grid.points("sample"), self._grid.resolution,
+			sx=np.float32(w1 / w0), sy=np.float32(h1 / h0), interpolation=interpolation))

@@ -1,0 +1,181 @@
+"""Minimal planar geometry for the dewarp stage: WKT in/out, area, validity.
+
+Origami reads and writes contours as WKT through shapely (ref: origami/batch/detect/dewarp.py:23-39,
+origami/batch/core/io.py:142-144); shapely/GEOS is not part of the MI355X image, so the few
+operations the dewarp stage needs are implemented here.  Text output follows GEOS 3.8's WKTWriter
+as driven by shapely 1.7's `geom.wkt` (trim on, 16 significant digits: C++ stream default float
+format, i.e. "%.16g"); area follows GEOS Area::ofRingSigned.
+"""
+
+import re
+
+import numpy as np
+
+_NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?|[-+]?(?:nan|inf)"
+_RING = re.compile(r"\(([^()]*)\)")
+
+
+class Geom:
+	"""A Polygon (rings[0] = shell, rest = holes) or a LineString (one ring)."""
+
+	__slots__ = ("geom_type", "rings")
+
+	def __init__(self, geom_type, rings):
+		if geom_type not in ("Polygon", "LineString"):
+			raise ValueError("unsupported geometry type %s" % geom_type)
+		self.geom_type = geom_type
+		self.rings = [np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]
+
+	@property
+	def is_empty(self):
+		return len(self.rings) == 0 or len(self.rings[0]) == 0
+
+	@property
+	def area(self):
+		if self.geom_type != "Polygon" or self.is_empty:
+			return 0.0
+		a = abs(ring_area_signed(self.rings[0]))
+		for hole in self.rings[1:]:
+			a -= abs(ring_area_signed(hole))
+		return a
+
+	@property
+	def is_valid(self):
+		if self.is_empty:
+			return True
+		if self.geom_type == "LineString":
+			r = self.rings[0]
+			return len(r) >= 2 and bool(np.all(np.isfinite(r))) and not bool(np.all(r == r[0]))
+		return all(_ring_is_valid(r) for r in self.rings) and _holes_inside(self.rings)
+
+	def transform(self, fn):
+		"""shapely.ops.transform: fn(xs, ys) -> (xs', ys') applied ring by ring."""
+		out = []
+		for r in self.rings:
+			x, y = fn(tuple(r[:, 0]), tuple(r[:, 1]))
+			out.append(np.stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)], axis=1))
+		return Geom(self.geom_type, out)
+
+	def with_rings(self, rings):
+		return Geom(self.geom_type, rings)
+
+	@property
+	def wkt(self):
+		return to_wkt(self)
+
+
+def ring_area_signed(ring):
+	n = len(ring)
+	if n < 3:
+		return 0.0
+	x = ring[1:n - 1, 0] - ring[0, 0]
+	total = 0.0
+	for xi, y_prev, y_next in zip(x, ring[0:n - 2, 1], ring[2:n, 1]):
+		total += xi * (y_prev - y_next)
+	return total / 2.0
+
+
+def _segments_cross(r):
+	"""True if any two non-adjacent segments of the closed ring r touch or cross."""
+	a, b = r[:-1], r[1:]
+	n = len(a)
+	if n < 3:
+		return False
+	d = b - a
+
+	def orient(p, q, s):  # sign of (q - p) x (s - p), broadcast
+		return np.sign((q[..., 0] - p[..., 0]) * (s[..., 1] - p[..., 1]) - (q[..., 1] - p[..., 1]) * (s[..., 0] - p[..., 0]))
+
+	A, B = a[:, None, :], b[:, None, :]
+	C, D = a[None, :, :], b[None, :, :]
+	o1, o2 = orient(A, B, C), orient(A, B, D)
+	o3, o4 = orient(C, D, A), orient(C, D, B)
+	proper = (o1 * o2 < 0) & (o3 * o4 < 0)
+
+	def on_seg(p, q, s, o):  # s collinear with pq and inside its bounding box
+		return (o == 0) & (np.minimum(p, q) <= s).all(-1) & (s <= np.maximum(p, q)).all(-1)
+
+	touch = on_seg(A, B, C, o1) | on_seg(A, B, D, o2) | on_seg(C, D, A, o3) | on_seg(C, D, B, o4)
+	i, j = np.indices((n, n))
+	gap = np.abs(i - j)
+	non_adjacent = (gap > 1) & (gap < n - 1)
+	del d
+	return bool(np.any((proper | touch) & non_adjacent))
+
+
+def _ring_is_valid(r):
+	if len(r) < 4 or not np.all(np.isfinite(r)):
+		return False
+	if not np.array_equal(r[0], r[-1]):
+		return False
+	if np.any(np.all(r[1:] == r[:-1], axis=1)) and len(np.unique(r, axis=0)) < 3:
+		return False
+	if ring_area_signed(r) == 0:
+		return False
+	return not _segments_cross(r)
+
+
+def _point_in_ring(p, r):
+	x, y = p
+	x0, y0 = r[:-1, 0], r[:-1, 1]
+	x1, y1 = r[1:, 0], r[1:, 1]
+	cond = (y0 > y) != (y1 > y)
+	with np.errstate(divide="ignore", invalid="ignore"):
+		xi = x0 + (y - y0) * (x1 - x0) / (y1 - y0)
+	return bool(np.count_nonzero(cond & (x < xi)) % 2)
+
+
+def _holes_inside(rings):
+	shell = rings[0]
+	return all(_point_in_ring(h[0], shell) for h in rings[1:])
+
+
+def parse_wkt(text):
+	"""POLYGON / LINESTRING (2-D) -> Geom."""
+	text = text.strip()
+	m = re.match(r"^(POLYGON|LINESTRING)\s*(Z\s*)?(EMPTY|\(.*\))\s*$", text, re.IGNORECASE | re.DOTALL)
+	if not m:
+		raise ValueError("unsupported WKT: %.40s" % text)
+	kind = "Polygon" if m.group(1).upper() == "POLYGON" else "LineString"
+	body = m.group(3)
+	if body.upper() == "EMPTY":
+		return Geom(kind, [])
+	if kind == "LineString":
+		parts = [body[1:-1]]
+	else:
+		parts = _RING.findall(body[1:-1])
+	rings = []
+	for part in parts:
+		nums = re.findall(_NUM, part, re.IGNORECASE)
+		n_coord = len(part.split(",")) if part.strip() else 0
+		if n_coord == 0:
+			rings.append(np.empty((0, 2)))
+			continue
+		dim = len(nums) // n_coord
+		if dim < 2 or dim * n_coord != len(nums):
+			raise ValueError("malformed WKT coordinates")
+		rings.append(np.array(nums, dtype=np.float64).reshape(n_coord, dim)[:, :2])
+	return Geom(kind, rings)
+
+
+def format_number(v):
+	"""GEOS 3.8 WKTWriter::writeNumber with trim: std::setprecision(16) on the default float format."""
+	if np.isnan(v):
+		return "nan"
+	if np.isinf(v):
+		return "inf" if v > 0 else "-inf"
+	return "%.16g" % v
+
+
+def _ring_text(r):
+	return "(" + ", ".join("%s %s" % (format_number(x), format_number(y)) for x, y in r) + ")"
+
+
+def to_wkt(geom):
+	if geom.geom_type == "Polygon":
+		if geom.is_empty:
+			return "POLYGON EMPTY"
+		return "POLYGON (" + ", ".join(_ring_text(r) for r in geom.rings) + ")"
+	if geom.is_empty:
+		return "LINESTRING EMPTY"
+	return "LINESTRING " + _ring_text(geom.rings[0])

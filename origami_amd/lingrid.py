@@ -1,0 +1,276 @@
+"""Robust linear inter-/extrapolation of scattered 2-D samples over a box — the MI355X build of
+origami/core/lingrid.py (same names, arguments and errors).
+
+Host side (this file): topology and the small sequential set-up — convex hull and Delaunay by
+Qhull (scipy.spatial), the border projections and corner values of the extrapolation point set
+(ref: lingrid.py:27-165, 192-250).  Device side (libogdewarp.so): every evaluation — point queries
+(K3, `ogd_tri_eval`, ref: lingrid.py:174-189, 286-290) and the dense lattice (K1b,
+`ogd_tri_rasterize`, ref: lingrid.py:252-282).  There is no CPU evaluation path.
+"""
+
+from enum import Enum
+from fractions import Fraction
+
+import numpy as np
+import scipy.spatial
+
+try:
+	from scipy.spatial import QhullError
+except ImportError:  # pragma: no cover  (scipy < 1.8)
+	from scipy.spatial.qhull import QhullError
+
+from . import _shim
+
+
+class Border(Enum):
+	LEFT = 1
+	TOP = 2
+	BOTTOM = 3
+	RIGHT = 4
+
+
+def lerp(a, b, x):
+	return (1 - x) * a + x * b
+
+
+class Box:
+	"""Outset bounding box that collects the extrapolation samples (ref: lingrid.py:27-165)."""
+
+	def __init__(self, minx, miny, maxx, maxy, margin=1):
+		self._minx, self._miny = minx - margin, miny - margin
+		self._maxx, self._maxy = maxx + margin, maxy + margin
+		self._box_size = max(maxx - minx, maxy - miny) + 2 * margin + 1
+		self._rows = []  # [x, y, value...] float64, in insertion order
+		self._tags = []  # per row: set of Border
+		self._corners = {}
+
+	@property
+	def points(self):
+		for row in self._rows:
+			yield row
+		for (cx, cy), val in self._corners.items():
+			yield np.hstack([[cx, cy], val])
+
+	def _intersect(self, p, direction):
+		"""First crossing of the ray p + u * direction (0 <= u <= box_size, |direction| = 1) with
+		the box outline, replacing shapely's LineString/LinearRing intersection (ref:
+		lingrid.py:62-93).  The coordinate of the border that is hit is returned exactly, so the
+		reference's equality test for border membership holds by construction."""
+		px, py = float(p[0]), float(p[1])
+		dx, dy = float(direction[0]), float(direction[1])
+		inside = self._minx < px < self._maxx and self._miny < py < self._maxy
+		if not inside:
+			raise ValueError("point %s outside given domain %s" % (
+				p, (self._minx, self._miny, self._maxx, self._maxy)))
+		wall_x = self._maxx if dx > 0 else self._minx
+		wall_y = self._maxy if dy > 0 else self._miny
+		ux = (wall_x - px) / dx if dx != 0 else np.inf
+		uy = (wall_y - py) / dy if dy != 0 else np.inf
+		u = ux if ux <= uy else uy
+		if not u <= self._box_size:
+			raise ValueError("point %s outside given domain, ray along %s does not hit the box" % (
+				p, direction))
+		x = wall_x if ux <= uy else px + u * dx
+		y = wall_y if uy <= ux else py + u * dy
+		tags = set()
+		if x == self._minx:
+			tags.add(Border.LEFT)
+		elif x == self._maxx:
+			tags.add(Border.RIGHT)
+		if y == self._miny:
+			tags.add(Border.TOP)
+		elif y == self._maxy:
+			tags.add(Border.BOTTOM)
+		return tags, x, y
+
+	def _add(self, tags, x, y, val):
+		self._rows.append(np.hstack([[x, y], val]).astype(np.float64))
+		self._tags.append(tags)
+
+	def add_projection(self, a, b):
+		"""Cast both end points of edge (a, b) along the edge normal onto the box
+		(ref: lingrid.py:95-104).  a, b: [x, y, value...]."""
+		a = np.asarray(a, dtype=np.float64)
+		b = np.asarray(b, dtype=np.float64)
+		v = a[:2] - b[:2]
+		if np.linalg.norm(v) < 1e-2:
+			return
+		normal = np.array([-v[1], v[0]])
+		normal /= np.linalg.norm(normal)
+		self._add(*self._intersect(a[:2], normal), a[2:])
+		self._add(*self._intersect(b[:2], normal), b[2:])
+
+	def _on(self, border):
+		return [row for row, tags in zip(self._rows, self._tags) if border in tags]
+
+	def _nearest_to_corner(self, border, f, axis):
+		rows = self._on(border)
+		if not rows:
+			return None
+		d = dict(x=0, y=1)[axis]
+		return f(rows, key=lambda pt: pt[d])
+
+	def _add_corner(self, cx, cy, p1, p2):
+		# ref: lingrid.py:106-130; the sympy projection is evaluated exactly (rationals), then rounded
+		if p1 is None and p2 is None:
+			return
+		if p1 is None:
+			val = p2[2:]
+		elif p2 is None:
+			val = p1[2:]
+		else:
+			a = (Fraction(float(p1[0])), Fraction(float(p1[1])))
+			e = (Fraction(float(p2[0])) - a[0], Fraction(float(p2[1])) - a[1])
+			ee = e[0] * e[0] + e[1] * e[1]
+			if ee == 0:
+				raise ValueError("Line requires two unique Points")
+			t = ((Fraction(float(cx)) - a[0]) * e[0] + (Fraction(float(cy)) - a[1]) * e[1]) / ee
+			p = np.array([float(a[0] + t * e[0]), float(a[1] + t * e[1])], dtype=np.float64)
+			d = np.linalg.norm(p - p1[:2])
+			d_total = np.linalg.norm(p2[:2] - p1[:2])
+			if d_total == 0:
+				return
+			val = lerp(p1[2:], p2[2:], d / d_total)
+		self._corners[(cx, cy)] = val
+
+	def add_corners(self):
+		# ref: lingrid.py:138-165 — top left, top right, bottom right, bottom left
+		near = self._nearest_to_corner
+		self._add_corner(self._minx, self._miny, near(Border.LEFT, min, "y"), near(Border.TOP, min, "x"))
+		self._add_corner(self._maxx, self._miny, near(Border.RIGHT, min, "y"), near(Border.TOP, max, "x"))
+		self._add_corner(self._maxx, self._maxy, near(Border.RIGHT, max, "y"), near(Border.BOTTOM, max, "x"))
+		self._add_corner(self._minx, self._maxy, near(Border.LEFT, max, "y"), near(Border.BOTTOM, min, "x"))
+
+
+class Interpolator:
+	"""Clip to bounds, evaluate the inner interpolant, fall back to the extrapolation where it is
+	NaN (ref: lingrid.py:168-189).  Evaluation runs on the GPU (K3)."""
+
+	def __init__(self, inter, extra, bounds, squeeze):
+		self._inter = inter  # _shim.Triangulation or None (collinear input)
+		self._extra = extra
+		self._bounds = bounds
+		self._squeeze = squeeze
+
+	@property
+	def bounds(self):
+		return self._bounds
+
+	@property
+	def triangulations(self):
+		return self._inter, self._extra
+
+	def __call__(self, pts):
+		pts = np.array(pts)
+		if len(pts.shape) == 1:
+			pts = pts[np.newaxis, :]
+		minx, miny, maxx, maxy = self._bounds
+		# clipping happens in the dtype of the query (float32 for Field.get), as in the reference
+		pts[:, 0] = np.clip(pts[:, 0], minx, maxx)
+		pts[:, 1] = np.clip(pts[:, 1], miny, maxy)
+		out = _shim.tri_eval(self._inter, self._extra, None, pts)
+		return out[:, 0] if self._squeeze else out
+
+	def ragged(self, pts, offsets):
+		"""Batch form for many rings: one wavefront per ring; clipping on the device (fp64)."""
+		out = _shim.tri_eval_ragged(self._inter, self._extra, self._bounds, pts, offsets)
+		return out[:, 0] if self._squeeze else out
+
+
+class InterpolatorFactory:
+	"""ref: lingrid.py:192-293."""
+
+	def __init__(self, points, values, bounds):
+		if len(values) < 2:
+			raise ValueError("not enough values given.")
+
+		self._points = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+		self._squeeze = not isinstance(values[0], np.ndarray)  # scalar vs vector values
+		self._values = np.asarray(values, dtype=np.float64)
+		if self._squeeze:
+			self._values = self._values.reshape(-1)
+		self._bounds = bounds
+
+		box = Box(*bounds)
+		pts, vals = self._points, self._values
+
+		try:
+			hull = scipy.spatial.ConvexHull(pts)  # vertices counter-clockwise in 2-D
+			self._is_collinear = False
+		except QhullError:
+			self._is_collinear = True  # most probably points are collinear
+
+		head_pts, head_val = [], []
+		if not self._is_collinear:
+			# of coincident input points the reference keeps the value of the last one (dict build)
+			last = dict(zip(map(tuple, pts.tolist()), range(len(pts))))
+			idx = [last[tuple(pts[i].tolist())] for i in hull.vertices]
+			ring = np.hstack([pts[hull.vertices], vals[idx].reshape(len(idx), -1)])
+			for a, b in zip(ring, np.roll(ring, -1, axis=0)):
+				box.add_projection(a, b)
+			head_pts = list(ring[:, :2])
+			head_val = list(ring[:, 2:])
+		else:
+			rows = np.hstack([pts, vals.reshape(len(pts), -1)])
+			for a, b in zip(rows, rows[1:]):
+				box.add_projection(a, b)
+				box.add_projection(b, a)
+
+		box.add_corners()
+		rows = list(box.points)
+		extra_pts = head_pts + [r[:2] for r in rows]
+		extra_val = head_val + [r[2:] for r in rows]
+		self._extra_pts = np.array(extra_pts, dtype=np.float64).reshape(-1, 2)
+		self._extra_val = np.array(extra_val, dtype=np.float64).reshape(len(extra_pts), -1)
+		if self._squeeze:
+			assert self._extra_val.shape[1] == 1
+			self._extra_val = self._extra_val[:, 0]
+		self._interpolator = None
+
+	@property
+	def extra_points(self):
+		return self._extra_pts
+
+	@property
+	def extra_values(self):
+		return self._extra_val
+
+	@property
+	def is_collinear(self):
+		return self._is_collinear
+
+	@staticmethod
+	def _triangulate(points, values):
+		# Qhull with scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"): the triangulation that
+		# LinearNDInterpolator builds internally (ref: lingrid.py:286-290)
+		tri = scipy.spatial.Delaunay(points)
+		return _shim.Triangulation(points, tri.simplices, values, tri.transform)
+
+	@property
+	def interpolator(self):
+		if self._interpolator is None:
+			extra = self._triangulate(self._extra_pts, self._extra_val)
+			inter = None
+			if not self._is_collinear:
+				inter = self._triangulate(self._points, self._values)
+			self._interpolator = Interpolator(inter, extra, self._bounds, self._squeeze)
+		return self._interpolator
+
+	@property
+	def grid(self):
+		"""Dense variant on the integer lattice [0..maxx] x [0..maxy], indexed [x, y] as the
+		reference's mgrid (ref: lingrid.py:252-282); rasterised on the GPU (K1b)."""
+		minx, miny, maxx, maxy = self._bounds
+		assert minx == 0 and miny == 0
+		inter, extra = self.interpolator.triangulations
+		nx, ny = int(maxx) + 1, int(maxy) + 1
+		pixels = _shim.tri_rasterize(inter, extra, None, 0.0, 0.0, 1.0, nx, ny, order="xy")
+		return pixels[:, :, 0] if self._squeeze else pixels
+
+
+def lingrid(points, values, width, height):
+	return InterpolatorFactory(points, values, (0, 0, width - 1, height - 1)).grid
+
+
+def lininterp(points, values, bounds):
+	return InterpolatorFactory(points, values, bounds).interpolator

@@ -1,0 +1,245 @@
+"""GPU parity of the HIP kernels against the CPU oracle, through the C ABI (ctypes).
+
+Bars (BASELINE.json north_star): label maps / integer work bit-exact; uint8 images within +-1 LSB on
+>= 99.9 % of pixels (here: bit-exact, both sides implement the same fixed-point arithmetic); float
+grid within 1e-3 px (here: bit-exact); fp64 interpolation within 1e-9 (bit-exact away from shared
+triangle edges)."""
+
+import numpy as np
+import pytest
+import scipy.interpolate
+
+from oracle import cv as ocv
+from oracle import lingrid as olin
+from origami_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _nodes(rng, h, w, s, amp=6.0):
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+	x = (gx - 1) * s + amp * np.sin(gy / 3.0) + rng.normal(0, 0.5, size=(h, w))
+	y = (gy - 1) * s + amp * np.cos(gx / 4.0) + rng.normal(0, 0.5, size=(h, w))
+	return np.stack([x, y], axis=-1).astype(np.float32)
+
+
+# ---- K1a ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("h,w,s", [(12, 9, 8), (12, 9, 25), (1, 1, 5), (2, 7, 1), (40, 33, 25), (5, 300, 7)])
+def test_grid_fill_bit_exact(gpu, h, w, s):
+	rng = np.random.default_rng(h * 1000 + w * 10 + s)
+	nodes = _nodes(rng, h, w, s)
+	got = gpu.grid_fill(nodes, s)
+	want = ocv.dense_grid(nodes, s)
+	assert got.shape == (h * s, w * s, 2)
+	np.testing.assert_array_equal(got, want)
+
+
+def test_grid_fill_scaled_copy(gpu):
+	rng = np.random.default_rng(7)
+	nodes = _nodes(rng, 10, 8, 25)
+	sx, sy = np.float32(1280 / 2400), np.float32(2400 / 3400)
+	got = gpu.grid_fill(nodes, 25, sx, sy)
+	want = ocv.dense_grid(nodes, 25)
+	want[:, :, 0] *= sx
+	want[:, :, 1] *= sy
+	np.testing.assert_array_equal(got, want)
+
+
+def test_grid_points_strided(gpu):
+	rng = np.random.default_rng(8)
+	nodes = _nodes(rng, 14, 11, 25)
+	got = gpu.grid_points_strided(nodes, 25, 25)
+	want = ocv.dense_grid(nodes, 25)[::25, ::25]
+	np.testing.assert_array_equal(got, want)
+
+
+def test_grid_sample_bilinear(gpu):
+	rng = np.random.default_rng(9)
+	nodes = _nodes(rng, 9, 8, 10)
+	dense = ocv.dense_grid(nodes, 10)
+	Hd, Wd = dense.shape[:2]
+	q = np.concatenate([
+		rng.uniform([-5, -5], [Hd + 5, Wd + 5], size=(500, 2)),
+		np.array([[0, 0], [Hd - 1, Wd - 1], [3, 4], [3.5, 4.0], [Hd, Wd]], dtype=np.float64)])
+	interp = scipy.interpolate.RegularGridInterpolator(
+		(np.arange(Hd), np.arange(Wd)), dense, method="linear", bounds_error=False, fill_value=None)
+	want = interp(q)
+	got = gpu.grid_sample_bilinear(nodes, 10, q)
+	np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+
+
+# ---- K2 -----------------------------------------------------------------------------------------
+
+def _map_with_edge_cases(rng, H, W, Hd, Wd):
+	yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+	m = np.stack([xx * (W / Wd) + 3 * np.sin(yy / 17), yy * (H / Hd) + 3 * np.cos(xx / 13)], axis=-1)
+	m += rng.normal(0, 0.3, size=m.shape)
+	m = m.astype(np.float32)
+	m[0, :8] = [[-0.5, -0.5], [0, 0], [0.5, 0.5], [W - 1, H - 1], [W - 0.5, H - 0.5], [W, H], [-1, -1], [-1.0001, 3]]
+	m[1, :6] = [[1.5, 2.5], [2.5, 3.5], [1e9, 1e9], [-1e9, 5], [np.nan, 2], [40000, 2]]
+	m[2, :4] = [[3.015625, 4.984375], [3.0156249, 4.9843751], [W - 1.5, 0.5], [0.5, H - 1.5]]
+	# exact 1/64 ties of the 1/32 rounding
+	m[3, :Wd] = np.stack([np.arange(Wd) * 0.25 + 1 / 64, np.full(Wd, 5 + 3 / 64)], axis=-1)
+	return m
+
+
+@pytest.mark.parametrize("C", [1, 3, 4])
+@pytest.mark.parametrize("interp", [ocv.INTER_LINEAR, ocv.INTER_NEAREST])
+def test_remap_bit_exact(gpu, C, interp):
+	rng = np.random.default_rng(100 + C)
+	H, W, Hd, Wd = 256, 256, 203, 277
+	src = rng.integers(0, 256, size=(H, W, C), dtype=np.uint8)
+	src[100:140, :, :] = np.where(np.arange(W)[None, :, None] % 7 < 3, 0, 255)  # hard edges
+	if C == 1:
+		src = src[:, :, 0]
+	m = _map_with_edge_cases(rng, H, W, Hd, Wd)
+	got = gpu.remap_u8(src, m, interp)
+	want = ocv.remap_u8(src, m, interp)
+	np.testing.assert_array_equal(got, want)
+
+
+def test_remap_strided_source_and_tiny_images(gpu):
+	rng = np.random.default_rng(5)
+	big = rng.integers(0, 256, size=(40, 64), dtype=np.uint8)
+	src = big[:, :37]  # row stride 64, width 37
+	m = rng.uniform(-2, 42, size=(31, 45, 2)).astype(np.float32)
+	np.testing.assert_array_equal(gpu.remap_u8(src, m), ocv.remap_u8(src, m))
+	one = np.array([[200]], dtype=np.uint8)
+	m1 = rng.uniform(-1.5, 1.5, size=(9, 9, 2)).astype(np.float32)
+	np.testing.assert_array_equal(gpu.remap_u8(one, m1), ocv.remap_u8(one, m1))
+	np.testing.assert_array_equal(gpu.remap_u8(one, m1, 0), ocv.remap_u8(one, m1, 0))
+
+
+def test_remap_label_map_through_scaled_grid(gpu):
+	"""layout.py:172-182: nearest remap of a label map through the page grid scaled to label size."""
+	rng = np.random.default_rng(11)
+	page = (600, 800)
+	warp = synth.Warp(page, 0.03, 0.02, 1, 2)
+	nodes = warp.node_grid(25)
+	labels = synth.label_map(rng, (320, 480), 4)
+	sx, sy = np.float32(320 / 600), np.float32(480 / 800)
+	want_map = ocv.dense_grid(nodes, 25)
+	want_map[:, :, 0] *= sx
+	want_map[:, :, 1] *= sy
+	want = ocv.remap_u8(labels, want_map, ocv.INTER_NEAREST)
+	got_fused = gpu.dewarp_u8(labels, nodes, 25, sx, sy, ocv.INTER_NEAREST)
+	got_unfused = gpu.remap_u8(labels, gpu.grid_fill(nodes, 25, sx, sy), ocv.INTER_NEAREST)
+	np.testing.assert_array_equal(got_fused, want)
+	np.testing.assert_array_equal(got_unfused, want)
+	assert set(np.unique(got_fused)) <= {0, 1, 2, 3}
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_fused_dewarp_equals_fill_then_remap(gpu, C):
+	rng = np.random.default_rng(21 + C)
+	page = (700, 500)
+	warp = synth.Warp(page, 0.04, 0.03, 2, 1)
+	nodes = warp.node_grid(25)
+	src = synth.text_page(rng, page, C)
+	want = ocv.remap_u8(src, ocv.dense_grid(nodes, 25))
+	got = gpu.dewarp_u8(src, nodes, 25)
+	np.testing.assert_array_equal(got, want)
+	# a page is mostly recovered, not blank
+	assert (got > 0).mean() > 0.5
+
+
+def test_remap_rejects_bad_arguments(gpu):
+	src = np.zeros((4, 4, 2), dtype=np.uint8)
+	m = np.zeros((4, 4, 2), dtype=np.float32)
+	with pytest.raises(gpu.OgdError):
+		gpu.remap_u8(src, m)
+	with pytest.raises(gpu.OgdError):
+		gpu.remap_u8(np.zeros((4, 4), dtype=np.uint8), m, 7)
+
+
+# ---- K3 / K1b -------------------------------------------------------------------------------------
+
+def _scattered(rng, n, size, vector=False):
+	W, H = size
+	pts = rng.uniform([0, 0], [W, H], size=(n, 2))
+	if vector:
+		vals = np.stack([pts[:, 0] * 0.9 + 3 * np.sin(pts[:, 1] / 50), pts[:, 1] * 1.1 + 2 * np.cos(pts[:, 0] / 40)], axis=1)
+	else:
+		vals = 0.03 * np.sin(pts[:, 0] / 100) + 0.02 * np.cos(pts[:, 1] / 130)
+	return pts, vals
+
+
+def _close(got, want, atol=1e-9):
+	assert got.shape == want.shape
+	assert np.array_equal(np.isnan(got), np.isnan(want))
+	np.testing.assert_allclose(got, want, rtol=0, atol=atol)
+	# identical containing triangle => identical bits; only shared-edge hits may differ
+	same = (got == want) | np.isnan(want)
+	assert same.mean() > 0.99
+
+
+@pytest.mark.parametrize("n,vector", [(64, False), (2000, False), (500, True), (4, False)])
+def test_tri_eval_matches_scipy(gpu, n, vector):
+	from origami_amd.lingrid import InterpolatorFactory
+	rng = np.random.default_rng(n + vector)
+	size = (600, 800)
+	pts, vals = _scattered(rng, n, size, vector)
+	bounds = (0, 0, size[0], size[1])
+	values = list(vals) if not vector else vals
+	want_f = olin.Factory(list(pts), values, bounds).interpolator()
+	got_f = InterpolatorFactory(list(pts), values, bounds).interpolator
+	q = np.concatenate([
+		rng.uniform([-50, -50], [size[0] + 50, size[1] + 50], size=(5000, 2)),
+		pts[:20],  # exactly on vertices
+		(pts[:20] + pts[1:21]) / 2,
+		np.array([[0, 0], [size[0], size[1]], [0, size[1]], [size[0], 0]], dtype=np.float64)])
+	_close(got_f(q), want_f(q))
+	q32 = q.astype(np.float32)  # Field.get queries in float32
+	_close(got_f(q32), want_f(q32))
+
+
+def test_tri_eval_collinear_and_errors(gpu):
+	from origami_amd.lingrid import InterpolatorFactory, lininterp
+	pts = [np.array([100.0, 100.0]), np.array([200.0, 150.0]), np.array([300.0, 200.0])]
+	vals = [0.01, 0.02, 0.04]
+	bounds = (0, 0, 600, 800)
+	want_f = olin.Factory(pts, vals, bounds).interpolator()
+	got_fac = InterpolatorFactory(pts, vals, bounds)
+	assert got_fac.is_collinear
+	rng = np.random.default_rng(0)
+	q = rng.uniform([0, 0], [600, 800], size=(1000, 2))
+	_close(got_fac.interpolator(q), want_f(q))
+	with pytest.raises(ValueError, match="not enough values"):
+		lininterp(pts[:1], vals[:1], bounds)
+
+
+def test_tri_eval_ragged_equals_flat(gpu):
+	from origami_amd.lingrid import InterpolatorFactory
+	rng = np.random.default_rng(3)
+	size = (600, 800)
+	pts, vals = _scattered(rng, 800, size, True)
+	f = InterpolatorFactory(pts, vals, (0, 0, size[0], size[1])).interpolator
+	rings = synth.polygon_rings(rng, size, 40, mu=30) + [np.empty((0, 2)), rng.uniform(0, 600, size=(1, 2))]
+	offsets = np.concatenate([[0], np.cumsum([len(r) for r in rings])]).astype(np.int64)
+	flat = np.concatenate(rings)
+	np.testing.assert_array_equal(f.ragged(flat, offsets), f(flat))
+
+
+@pytest.mark.parametrize("vector", [False, True])
+def test_tri_rasterize_matches_griddata(gpu, vector):
+	from origami_amd.lingrid import lingrid
+	rng = np.random.default_rng(17 + vector)
+	W, H = 150, 110
+	pts, vals = _scattered(rng, 300, (W - 1, H - 1), vector)
+	values = list(vals) if not vector else vals
+	want = olin.lingrid(list(pts), values, W, H)
+	got = lingrid(list(pts), values, W, H)
+	assert got.shape == want.shape == ((W, H, 2) if vector else (W, H))
+	_close(got, want)
+
+
+def test_tri_rasterize_equals_point_queries(gpu):
+	from origami_amd.lingrid import InterpolatorFactory
+	rng = np.random.default_rng(23)
+	pts, vals = _scattered(rng, 500, (299, 199), False)
+	fac = InterpolatorFactory(list(pts), list(vals), (0, 0, 299, 199))
+	dense = fac.grid
+	xs, ys = np.mgrid[0:300, 0:200]
+	q = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.float64)
+	np.testing.assert_array_equal(dense.ravel(), fac.interpolator(q))
