@@ -187,7 +187,7 @@ def test_tri_eval_matches_scipy(gpu, n, vector):
 	q = np.concatenate([
 		rng.uniform([-50, -50], [size[0] + 50, size[1] + 50], size=(5000, 2)),
 		pts[:20],  # exactly on vertices
-		(pts[:20] + pts[1:21]) / 2,
+		(pts[:-1][:20] + pts[1:][:20]) / 2,
 		np.array([[0, 0], [size[0], size[1]], [0, size[1]], [size[0], 0]], dtype=np.float64)])
 	_close(got_f(q), want_f(q))
 	q32 = q.astype(np.float32)  # Field.get queries in float32
