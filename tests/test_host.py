@@ -1,0 +1,145 @@
+"""Host-side logic of the product (no GPU): artifact I/O, WKT geometry, and the extrapolation point set
+of lingrid, which is built on the host and only evaluated on the device."""
+
+import io
+import json
+import zipfile
+
+import numpy as np
+import pytest
+
+from oracle import lingrid as olin
+from origami_amd import geometry, synth
+from origami_amd.dewarp import Geometry, Grid, Samples
+from origami_amd.lingrid import InterpolatorFactory
+
+
+# ---- artifacts (ref: origami/core/dewarp.py:43-75, 537-553; docs/formats.md) ---------------------------
+
+def test_samples_round_trip_and_format():
+	s = Samples(Geometry(2400, 3400))
+	s.append(np.array([10.0, 20.0]), 0.01)
+	s.extend([np.array([30.5, 40.25])], [-0.02])
+	buf = io.BytesIO()
+	with zipfile.ZipFile(buf, "w") as zf:
+		s.save(zf, "h")
+		Samples(Geometry(2400, 3400)).save(zf, "v")
+	with zipfile.ZipFile(buf, "r") as zf:
+		assert sorted(zf.namelist()) == ["h.json", "h.npy", "v.json", "v.npy"]
+		assert json.loads(zf.read("h.json")) == {"version": 1, "size": [2400, 3400]}
+		arr = np.load(io.BytesIO(zf.read("h.npy")))
+		assert arr.dtype == np.float64 and arr.shape == (2, 3)
+		np.testing.assert_array_equal(arr, [[10, 20, 0.01], [30.5, 40.25, -0.02]])
+		assert np.load(io.BytesIO(zf.read("v.npy"))).shape == (3, 0)  # empty case, dewarp.py:65-66
+		h = Samples.open(zf, "h")
+		v = Samples.open(zf, "v")
+	assert len(h) == 2 and h.geometry.size == (2400, 3400)
+	np.testing.assert_array_equal(np.array(h.points), [[10, 20], [30.5, 40.25]])
+	assert h.values == [0.01, -0.02]
+	assert len(v.values) == 0 and np.asarray(v.points).shape == (2, 0)  # dewarp.py:55-57
+
+
+def test_grid_save_open_round_trip(tmp_path):
+	nodes = synth.Warp((600, 800)).node_grid(25)
+	grid = Grid(nodes, 25)
+	path = tmp_path / "dewarp.zip"
+	grid.save(path)
+	with zipfile.ZipFile(path) as zf:
+		assert zf.namelist() == ["data.npy", "meta.json"]  # data first, dewarp.py:552-553
+		meta = json.loads(zf.read("meta.json"))
+		assert meta == {"version": 1, "cell": 25, "shape": list(nodes.shape)}
+		data = np.load(io.BytesIO(zf.read("data.npy")))
+		assert data.dtype == np.float32
+		assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in zf.infolist())
+	again = Grid.open(path)
+	assert again.resolution == 25
+	np.testing.assert_array_equal(again.points("sample"), nodes)
+	h, w = nodes.shape[:2]
+	assert again.geometry.size == (w * 25, h * 25)
+	assert Geometry(300, 400).rel_area(0.01) == pytest.approx((500 * 0.01) ** 2)
+
+
+# ---- lingrid host part against the oracle ---------------------------------------------------------------
+
+@pytest.mark.parametrize("n,vector", [(5, False), (64, False), (300, True)])
+def test_extrapolation_set_equals_oracle(n, vector):
+	rng = np.random.default_rng(n)
+	pts = rng.uniform([0, 0], [600, 800], size=(n, 2))
+	if vector:
+		vals = np.stack([pts[:, 0] * 0.9 + 3, pts[:, 1] * 1.1 - 2], axis=1)
+		values = vals
+	else:
+		values = list(0.03 * np.sin(pts[:, 0] / 100))
+	bounds = (0, 0, 600, 800)
+	want = olin.Factory(list(pts), values, bounds)
+	got = InterpolatorFactory(list(pts), values, bounds)
+	assert got.is_collinear == want.is_collinear
+	np.testing.assert_array_equal(got.extra_points, want.extra_pts)
+	np.testing.assert_array_equal(got.extra_values, want.extra_val)
+
+
+def test_extrapolation_set_collinear_and_duplicates():
+	pts = [np.array([100.0, 100.0]), np.array([200.0, 150.0]), np.array([300.0, 200.0])]
+	vals = [0.01, 0.02, 0.04]
+	want = olin.Factory(pts, vals, (0, 0, 600, 800))
+	got = InterpolatorFactory(pts, vals, (0, 0, 600, 800))
+	assert got.is_collinear and want.is_collinear
+	np.testing.assert_array_equal(got.extra_points, want.extra_pts)
+	np.testing.assert_array_equal(got.extra_values, want.extra_val)
+	# coincident samples: the value of the last one wins (dict build, lingrid.py:217-218)
+	rng = np.random.default_rng(0)
+	p = rng.uniform(0, 500, size=(20, 2))
+	p = np.vstack([p, p[:3]])
+	v = list(np.arange(23, dtype=np.float64))
+	want = olin.Factory(list(p), v, (0, 0, 500, 500))
+	got = InterpolatorFactory(list(p), v, (0, 0, 500, 500))
+	np.testing.assert_array_equal(got.extra_values, want.extra_val)
+
+
+def test_lininterp_argument_errors():
+	with pytest.raises(ValueError, match="not enough values given."):
+		InterpolatorFactory([np.zeros(2)], [1.0], (0, 0, 10, 10))
+	with pytest.raises(ValueError, match="outside given domain"):
+		InterpolatorFactory(
+			[np.array([0.0, 0.0]), np.array([50.0, 5.0]), np.array([20.0, 40.0])], [1.0, 2.0, 3.0], (10, 10, 60, 60))
+
+
+# ---- WKT / geometry (ref: origami/batch/detect/dewarp.py:23-39) ----------------------------------------
+
+def test_wkt_round_trip_and_number_format():
+	text = "POLYGON ((0 0, 10.5 0, 10.5 7.25, 0 7.25, 0 0), (2 2, 3 2, 3 3, 2 2))"
+	g = geometry.parse_wkt(text)
+	assert g.geom_type == "Polygon" and len(g.rings) == 2
+	assert g.wkt == text
+	assert g.area == pytest.approx(10.5 * 7.25 - 0.5)
+	ls = geometry.parse_wkt("LINESTRING (1.5 2, 3 4.125, 1e3 -2.5e-3)")
+	assert ls.geom_type == "LineString" and ls.area == 0.0
+	assert ls.wkt == "LINESTRING (1.5 2, 3 4.125, 1000 -0.0025)"
+	assert geometry.format_number(0.1 + 0.2) == "0.3"  # 16 significant digits, trimmed
+	assert geometry.format_number(1 / 3) == "0.3333333333333333"
+	assert geometry.format_number(4687.500000000001) == "4687.500000000001"
+	assert geometry.parse_wkt("POLYGON EMPTY").is_empty
+
+
+def test_validity_and_transform():
+	square = geometry.parse_wkt("POLYGON ((0 0, 4 0, 4 4, 0 4, 0 0))")
+	bowtie = geometry.parse_wkt("POLYGON ((0 0, 4 4, 4 0, 0 4, 0 0))")
+	assert square.is_valid and not bowtie.is_valid
+	moved = square.transform(lambda x, y: (np.asarray(x) + 1, np.asarray(y) * 2))
+	assert moved.wkt == "POLYGON ((1 0, 5 0, 5 8, 1 8, 1 0))"
+	assert moved.area == 32
+	with pytest.raises(ValueError):
+		geometry.parse_wkt("MULTIPOLYGON (((0 0, 1 0, 1 1, 0 0)))")
+
+
+def test_synthetic_page_dir_layout(tmp_path):
+	rng = np.random.default_rng(5)
+	page = synth.write_page_dir(tmp_path, "page0001", rng, size=(300, 400), n_h=20, n_v=30, n_regions=5, n_separators=2, label_size=(160, 208))
+	out = page.with_suffix(".out")
+	assert sorted(p.name for p in out.iterdir()) == ["contours.0.zip", "flow.zip", "segment.zip"]
+	with zipfile.ZipFile(out / "contours.0.zip") as zf:
+		names = zf.namelist()
+		assert "meta.json" in names and "separators/V/meta.json" in names
+		assert sum(n.startswith("regions/TEXT/") for n in names) == 5
+		g = geometry.parse_wkt(zf.read("regions/TEXT/0.wkt").decode("utf8"))
+		assert g.geom_type == "Polygon" and g.area > 0

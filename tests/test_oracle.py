@@ -1,0 +1,264 @@
+"""CPU tests of the oracle itself (no GPU): hand-derived known answers for the restated cv2 calls,
+the scipy-backed interpolation against scipy called directly, and the committed golden fixtures.
+
+The reference holds no tests or fixtures for this path, so the known answers below are
+derived by hand from the published OpenCV 4.2 arithmetic — PARITY UNPINNED for
+the cv2 part."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.interpolate
+
+from oracle import cv as ocv
+from oracle import dewarp as odw
+from oracle import lingrid as olin
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def golden(name):
+	return np.load(GOLDEN / ("%s.npz" % name), allow_pickle=False)
+
+
+# ---- cv2.resize(INTER_LINEAR) restatement ------------------------------------------------------------
+
+def test_resize_known_answer_2x2():
+	# the classic cv2.resize([[0, 1], [2, 3]], (4, 4)) result: taps at -0.25, 0.25, 0.75, 1.25 (clamped)
+	src = np.array([[0, 1], [2, 3]], dtype=np.float32)
+	want = np.array([
+		[0.0, 0.25, 0.75, 1.0],
+		[0.5, 0.75, 1.25, 1.5],
+		[1.5, 1.75, 2.25, 2.5],
+		[2.0, 2.25, 2.75, 3.0]], dtype=np.float32)
+	np.testing.assert_array_equal(ocv.resize_linear_f32(src, 2), want)
+
+
+@pytest.mark.parametrize("s", [1, 5, 25])
+def test_resize_nodes_sit_on_cell_centres(s):
+	# odd cell: node g lands exactly on dense pixel g*s + (s-1)/2; edges are flat
+	rng = np.random.default_rng(s)
+	src = rng.normal(0, 100, size=(6, 7)).astype(np.float32)
+	dense = ocv.resize_linear_f32(src, s)
+	assert dense.shape == (6 * s, 7 * s)
+	c = (s - 1) // 2
+	np.testing.assert_array_equal(dense[c::s, c::s], src)
+	# columns beyond the last node centre are exactly flat (x taps are clamped with weight 0) ...
+	np.testing.assert_array_equal(dense[:, -c - 1:], np.repeat(dense[:, -c - 1:][:, :1], c + 1, axis=1))
+	# ... rows above the first node centre only up to fp32 rounding: the y weights keep their fraction
+	# and blend the clipped row with itself (v * (1 - f) + v * f)
+	np.testing.assert_allclose(dense[:c + 1, :], np.repeat(dense[c:c + 1, :], c + 1, axis=0), rtol=3e-7)
+
+
+def test_resize_reproduces_affine_planes():
+	gy, gx = np.mgrid[0:9, 0:11].astype(np.float32)
+	plane = (3 * gx - 2 * gy + 7).astype(np.float32)
+	dense = ocv.resize_linear_f32(plane, 8)
+	X = (np.arange(11 * 8) + 0.5) / 8 - 0.5
+	Y = (np.arange(9 * 8) + 0.5) / 8 - 0.5
+	inside = dense[4:-4, 4:-4]
+	want = 3 * X[None, 4:-4] - 2 * Y[4:-4, None] + 7
+	np.testing.assert_allclose(inside, want, atol=1e-4)
+
+
+# ---- cv2.remap restatement ---------------------------------------------------------------------------
+
+SRC4 = np.array([[10, 20], [30, 40]], dtype=np.uint8)
+
+
+def _remap1(x, y, interp=ocv.INTER_LINEAR, src=SRC4):
+	m = np.array([[[x, y]]], dtype=np.float32)
+	return int(ocv.remap_u8(src, m, interp)[0, 0])
+
+
+def test_remap_linear_known_answers():
+	assert _remap1(0, 0) == 10 and _remap1(1, 0) == 20 and _remap1(0, 1) == 30 and _remap1(1, 1) == 40
+	# centre: the mean, (8192 * 100 + 16384) >> 15 = 25
+	assert _remap1(0.5, 0.5) == (8192 * (10 + 20 + 30 + 40) + 16384) >> 15
+	# 1/32 steps: x = 0.25 -> fx = 8
+	assert _remap1(0.25, 0) == (24 * 32 * 32 * 10 + 8 * 32 * 32 * 20 + 16384) >> 15
+	# coordinates are rounded to 1/32 px, half-to-even: 1/64 -> 0, 3/64 -> 2/32
+	assert _remap1(1 / 64, 0) == 10
+	assert _remap1(3 / 64, 0) == (30 * 32 * 32 * 10 + 2 * 32 * 32 * 20 + 16384) >> 15
+	# BORDER_CONSTANT 0 blends in at the edges, fully outside is 0
+	assert _remap1(-0.5, 0) == (16 * 32 * 32 * 10 + 16384) >> 15
+	assert _remap1(1.5, 1) == (16 * 32 * 32 * 40 + 16384) >> 15
+	assert _remap1(-1, 0) == 0 and _remap1(2, 0) == 0 and _remap1(0, 2.0) == 0
+	assert _remap1(np.nan, 0) == 0 and _remap1(1e9, 0) == 0 and _remap1(-1e9, 0) == 0
+
+
+def test_remap_nearest_known_answers():
+	n = ocv.INTER_NEAREST
+	assert _remap1(0.49, 0, n) == 10 and _remap1(0.51, 0, n) == 20
+	assert _remap1(0.5, 0, n) == 10  # round-half-even: 0.5 -> 0
+	assert _remap1(1.5, 1.5, n) == 0  # 1.5 -> 2 = outside
+	assert _remap1(-0.5, 0, n) == 10  # -0.5 -> -0
+	assert _remap1(-0.51, 0, n) == 0
+	assert _remap1(np.nan, 0, n) == 0 and _remap1(70000, 0, n) == 0
+
+
+def test_remap_identity_map_is_identity():
+	rng = np.random.default_rng(0)
+	src = rng.integers(0, 256, size=(17, 23, 3), dtype=np.uint8)
+	yy, xx = np.mgrid[0:17, 0:23].astype(np.float32)
+	m = np.stack([xx, yy], axis=-1)
+	for interp in (ocv.INTER_LINEAR, ocv.INTER_NEAREST):
+		np.testing.assert_array_equal(ocv.remap_u8(src, m, interp), src)
+
+
+def test_remap_linear_is_within_one_lsb_of_float_bilinear_on_quantised_coords():
+	rng = np.random.default_rng(1)
+	src = rng.integers(0, 256, size=(40, 50), dtype=np.uint8)
+	q = rng.integers(0, 32 * 38, size=(30, 30, 2)).astype(np.float32) / 32  # exact 1/32 coordinates
+	got = ocv.remap_u8(src, q).astype(np.float64)
+	x, y = q[..., 0].astype(np.float64), q[..., 1].astype(np.float64)
+	ix, iy = np.floor(x).astype(int), np.floor(y).astype(int)
+	fx, fy = x - ix, y - iy
+	s = src.astype(np.float64)
+	want = (s[iy, ix] * (1 - fx) + s[iy, ix + 1] * fx) * (1 - fy) + (s[iy + 1, ix] * (1 - fx) + s[iy + 1, ix + 1] * fx) * fy
+	assert np.abs(got - want).max() <= 0.5 + 1e-9
+
+
+def test_threads_do_not_change_results():
+	rng = np.random.default_rng(2)
+	nodes = rng.normal(0, 50, size=(7, 9, 2)).astype(np.float32)
+	np.testing.assert_array_equal(ocv.dense_grid(nodes, 11, threads=1), ocv.dense_grid(nodes, 11, threads=4))
+
+
+# ---- lingrid restatement against scipy called directly -----------------------------------------------
+
+def test_lininterp_inside_hull_is_scipy_linear_nd():
+	rng = np.random.default_rng(3)
+	pts = rng.uniform([0, 0], [600, 800], size=(200, 2))
+	vals = np.sin(pts[:, 0] / 90) + np.cos(pts[:, 1] / 70)
+	f = olin.lininterp(list(pts), list(vals), (0, 0, 600, 800))
+	direct = scipy.interpolate.LinearNDInterpolator(pts, vals)
+	q = rng.uniform([0, 0], [600, 800], size=(2000, 2))
+	d = direct(q)
+	inside = ~np.isnan(d)
+	assert inside.sum() > 1000
+	np.testing.assert_array_equal(f(q)[inside], d[inside])
+	assert not np.any(np.isnan(f(q)))  # the extrapolation covers the rest of the box
+
+
+def test_lininterp_extrapolation_set_structure():
+	# hull (CCW) + two projections per hull edge + four corners, corners last in TL, TR, BR, BL order
+	pts = [np.array(p, dtype=np.float64) for p in [(100, 100), (500, 120), (480, 700), (90, 650), (300, 400)]]
+	vals = [1.0, 2.0, 3.0, 4.0, 5.0]
+	fac = olin.Factory(pts, vals, (0, 0, 600, 800))
+	assert not fac.is_collinear
+	assert len(fac.extra_pts) == 4 + 2 * 4 + 4
+	np.testing.assert_array_equal(fac.extra_pts[-4:], [[-1, -1], [601, -1], [601, 801], [-1, 801]])
+	# every projected point lies on the outset box
+	proj = fac.extra_pts[4:-4]
+	on_box = (proj[:, 0] == -1) | (proj[:, 0] == 601) | (proj[:, 1] == -1) | (proj[:, 1] == 801)
+	assert on_box.all()
+	# values of the projections are those of the hull vertices they come from
+	assert set(fac.extra_val[4:-4]) <= {1.0, 2.0, 3.0, 4.0}
+
+
+def test_lininterp_clips_queries_to_bounds():
+	rng = np.random.default_rng(4)
+	pts = rng.uniform([0, 0], [100, 100], size=(30, 2))
+	vals = rng.normal(size=30)
+	f = olin.lininterp(list(pts), list(vals), (0, 0, 100, 100))
+	np.testing.assert_array_equal(f(np.array([[-50.0, 20.0], [150.0, 200.0]])), f(np.array([[0.0, 20.0], [100.0, 100.0]])))
+
+
+def test_lininterp_collinear_and_too_few():
+	pts = [np.array([100.0, 100.0]), np.array([200.0, 150.0]), np.array([300.0, 200.0])]
+	fac = olin.Factory(pts, [0.01, 0.02, 0.04], (0, 0, 600, 800))
+	assert fac.is_collinear
+	out = fac.interpolator()(np.array([[200.0, 150.0], [0.0, 0.0], [600.0, 800.0]]))
+	assert not np.any(np.isnan(out))
+	# only the border projections carry values in the collinear case (lingrid.py:228-237), so even a
+	# sample point is not reproduced exactly; results stay within the sample range
+	assert np.all((out >= 0.01 - 1e-12) & (out <= 0.04 + 1e-12))
+	with pytest.raises(ValueError, match="not enough values"):
+		olin.lininterp(pts[:1], [0.5], (0, 0, 600, 800))
+
+
+def test_field_constant_for_two_samples():
+	f = odw.Field(odw.Samples((600, 800), [np.zeros(2), np.ones(2)], [0.1, 0.2]), (600, 800), np.pi / 2)
+	d = f.get(np.zeros((5, 2), dtype=np.float32))
+	assert d.dtype == np.float32 and d.shape == (5, 2)
+	np.testing.assert_allclose(d, np.tile([np.cos(np.float32(np.pi / 2)), 1.0], (5, 1)), atol=1e-7)
+
+
+# ---- golden fixtures ----------------------------------------------------------------------------------
+
+def test_golden_field():
+	g = golden("field")
+	size = tuple(int(v) for v in g["size"])
+	probes = g["probes"]
+	f64 = odw.Field(odw.Samples(size, list(g["n64_points"]), list(g["n64_values"])), size, 0)
+	np.testing.assert_array_equal(f64.get(probes.copy()), g["n64_field"])
+	f3 = odw.Field(odw.Samples(size, list(g["n3_points"]), list(g["n3_values"])), size, 0)
+	np.testing.assert_array_equal(f3.get(probes.copy()), g["n3_field"])
+	f2 = odw.Field(odw.Samples(size, list(g["n3_points"][:2]), list(g["n3_values"][:2])), size, np.pi / 2)
+	np.testing.assert_array_equal(f2.get(probes.copy()), g["n2_field"])
+
+
+def test_golden_grid_create():
+	g = golden("grid")
+	size = tuple(int(v) for v in g["size"])
+	grid = odw.Grid.create(
+		size, odw.Samples(size, list(g["h_points"]), list(g["h_values"])),
+		odw.Samples(size, list(g["v_points"]), list(g["v_values"])), grid_res=25)
+	assert grid.hv.dtype == np.float32
+	np.testing.assert_array_equal(grid.hv, g["grid_hv"])
+	hv = grid.hv
+	# the grid covers the page: border nodes lie outside on every side (dewarp.py:341-419)
+	# (rows / columns appended later by the other axis' extension may poke back in by < 1 cell)
+	assert hv[:, 0, 0].max() < 25 and hv[:, -1, 0].min() > size[0] - 25
+	assert hv[0, :, 1].max() <= 0 and hv[-1, :, 1].min() >= size[1]
+	# neighbouring nodes are about one cell apart
+	dx = np.linalg.norm(hv[:, 1:] - hv[:, :-1], axis=-1)
+	assert 10 < dx.min() and dx.max() < 40
+
+
+def test_golden_dense_and_inverse():
+	g = golden("dense")
+	for s in (8, 25):
+		np.testing.assert_array_equal(ocv.dense_grid(g["nodes_s%d" % s], s), g["dense_s%d" % s])
+	got = odw.Grid(g["nodes_s8"], 8).inverse(g["inverse_q_xy"])
+	np.testing.assert_allclose(got, g["inverse_s8"], rtol=0, atol=1e-9)
+
+
+def test_golden_remap():
+	g = golden("remap")
+	src, m = g["src_rgb"], g["map"]
+	gray = np.ascontiguousarray(src[:, :, 0])
+	np.testing.assert_array_equal(ocv.remap_u8(gray, m, ocv.INTER_LINEAR), g["gray_linear"])
+	np.testing.assert_array_equal(ocv.remap_u8(gray, m, ocv.INTER_NEAREST), g["gray_nearest"])
+	np.testing.assert_array_equal(ocv.remap_u8(src, m, ocv.INTER_LINEAR), g["rgb_linear"])
+	np.testing.assert_array_equal(ocv.remap_u8(src, m, ocv.INTER_NEAREST), g["rgb_nearest"])
+	# per-channel arithmetic: channel 0 of the RGB result is the gray result
+	np.testing.assert_array_equal(g["rgb_linear"][:, :, 0], g["gray_linear"])
+
+
+def test_golden_transformer():
+	g = golden("transformer")
+	grid = odw.Grid(g["nodes"], 25)
+	off = g["ring_offsets"]
+	rings = [g["ring_points"][a:b] for a, b in zip(off[:-1], off[1:])]
+	got = np.concatenate(odw.transform_rings(grid.transformer, rings))
+	np.testing.assert_allclose(got, g["ring_warped"], rtol=0, atol=1e-9)
+	size = tuple(int(v) for v in g["size"])
+	np.testing.assert_array_equal(odw.dewarped(g["page"], grid), g["page_dewarped"])
+	np.testing.assert_array_equal(
+		odw.dewarp_image(size, g["labels"], grid, ocv.INTER_NEAREST), g["labels_dewarped"])
+
+
+def test_transformer_inverts_the_grid():
+	# forward map (warped -> dewarped) of the dense grid's own samples gives back their pixel position
+	g = golden("transformer")
+	grid = odw.Grid(g["nodes"], 25)
+	full = grid.points_full()
+	ys, xs = np.mgrid[30:full.shape[0] - 30:40, 30:full.shape[1] - 30:40]
+	src = full[ys, xs].reshape(-1, 2).astype(np.float64)
+	x, y = grid.transformer(tuple(src[:, 0]), tuple(src[:, 1]))
+	err = np.hypot(x - xs.ravel(), y - ys.ravel())
+	# piecewise-linear over Delaunay triangles vs bilinear over cells offset by half a cell
+	assert np.median(err) < 0.5 and err.max() < 3
