@@ -11,116 +11,19 @@
 //             entry fx = fy = 0 is stored as {32767, 0, 0, 1}, which gives the same byte.)
 //   nearest: ix = sat_i16(cvRound(mx)), iy likewise; dst = P(ix, iy).
 //
-// HBM traffic per output pixel: 8 B of map read + C B written + ~C B of source (each source byte is
-// read from HBM once; neighbouring taps hit L1/L2).  One thread owns 4 adjacent output pixels: the
-// map is read as two 16-byte loads, the result is written as one 4*C-byte store, and a wavefront
-// covers 256 pixels of one output row, so the source window it gathers from is a few cache lines.
+// HBM traffic per output pixel: 8 B of map read + C B written + ~C B of source.  K2 proper (materialised
+// map) is the LDS-tiled remap_u8_wave_kernel of ogd_remap_lds.h; the fused kernel below recomputes the
+// map from the node grid and gathers from global memory.
 #include "ogd_common.h"
 #include "ogd_resize_math.h"
+#include "ogd_remap_math.h"
+#include "ogd_remap_lds.h"
 
 namespace ogd {
 
 constexpr int RM_TX = 64;  // threads along x (one wavefront = one row segment)
 constexpr int RM_TY = 4;   // rows per block
 constexpr int RM_PX = 4;   // pixels per thread
-
-__device__ __forceinline__ int cv_round(float v) {
-  const float r = rintf(v);
-  return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : INT_MIN;
-}
-
-__device__ __forceinline__ int sat_i16(int v) { return min(max(v, -32768), 32767); }
-
-template <int C>
-__device__ __forceinline__ void sample_linear(const uint8_t* __restrict__ src, int H, int W,
-                                              ptrdiff_t ss, float mx, float my, uint8_t* o) {
-  const int sx = cv_round(__fmul_rn(mx, 32.f)), sy = cv_round(__fmul_rn(my, 32.f));
-  const int ix = sat_i16(sx >> 5), iy = sat_i16(sy >> 5);
-  const int a1 = sx & 31, b1 = sy & 31, a0 = 32 - a1, b0 = 32 - b1;
-  if ((unsigned)ix < (unsigned)max(W - 1, 0) && (unsigned)iy < (unsigned)max(H - 1, 0)) {
-    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int top = a0 * p[c] + a1 * p[C + c];
-      const int bot = a0 * p[ss + c] + a1 * p[ss + C + c];
-      o[c] = (uint8_t)((b0 * top + b1 * bot + 512) >> 10);
-    }
-  } else if (ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = 0;
-  } else {
-    const bool x0 = ix >= 0, x1 = ix + 1 < W, y0 = iy >= 0, y1 = iy + 1 < H;
-    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int v00 = (x0 && y0) ? p[c] : 0, v01 = (x1 && y0) ? p[C + c] : 0;
-      const int v10 = (x0 && y1) ? p[ss + c] : 0, v11 = (x1 && y1) ? p[ss + C + c] : 0;
-      o[c] = (uint8_t)((b0 * (a0 * v00 + a1 * v01) + b1 * (a0 * v10 + a1 * v11) + 512) >> 10);
-    }
-  }
-}
-
-template <int C>
-__device__ __forceinline__ void sample_nearest(const uint8_t* __restrict__ src, int H, int W,
-                                               ptrdiff_t ss, float mx, float my, uint8_t* o) {
-  const int ix = sat_i16(cv_round(mx)), iy = sat_i16(cv_round(my));
-  if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
-    const uint8_t* p = src + (ptrdiff_t)iy * ss + (ptrdiff_t)ix * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = p[c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = 0;
-  }
-}
-
-template <int C, int INTERP>
-__device__ __forceinline__ void sample(const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss,
-                                       float mx, float my, uint8_t* o) {
-  if (INTERP == OGD_INTER_LINEAR)
-    sample_linear<C>(src, H, W, ss, mx, my, o);
-  else
-    sample_nearest<C>(src, H, W, ss, mx, my, o);
-}
-
-template <int N>
-__device__ __forceinline__ void store_bytes(uint8_t* dst, const uint8_t* v) {
-  // N is a multiple of 4: dword stores at byte alignment (gfx950 runs in unaligned access mode)
-#pragma unroll
-  for (int k = 0; k < N; k += 4) {
-    uint32_t u = (uint32_t)v[k] | ((uint32_t)v[k + 1] << 8) | ((uint32_t)v[k + 2] << 16) |
-                 ((uint32_t)v[k + 3] << 24);
-    __builtin_memcpy(dst + k, &u, 4);
-  }
-}
-
-struct __attribute__((aligned(8))) map4 {
-  float v[8];
-};
-
-template <int C, int INTERP>
-__global__ __launch_bounds__(RM_TX* RM_TY) void remap_u8_kernel(
-    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float* __restrict__ map,
-    int Hd, int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds) {
-  const int X = (blockIdx.x * RM_TX + threadIdx.x) * RM_PX;
-  const int Y = blockIdx.y * RM_TY + threadIdx.y;
-  if (X >= Wd || Y >= Hd) return;
-  const float* m = map + ((size_t)Y * Wd + X) * 2;
-  uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
-  uint8_t o[RM_PX * C];
-  if (X + RM_PX <= Wd) {
-    const map4 mv = *reinterpret_cast<const map4*>(m);
-#pragma unroll
-    for (int k = 0; k < RM_PX; ++k)
-      sample<C, INTERP>(src, H, W, ss, mv.v[2 * k], mv.v[2 * k + 1], o + k * C);
-    store_bytes<RM_PX * C>(d, o);
-  } else {
-    for (int k = 0; X + k < Wd; ++k) {
-      sample<C, INTERP>(src, H, W, ss, m[2 * k], m[2 * k + 1], o);
-      for (int c = 0; c < C; ++c) d[k * C + c] = o[c];
-    }
-  }
-}
 
 // Fused variant: the map value of every output pixel is recomputed from the node grid (K1a
 // arithmetic, bit-identical to grid_fill_kernel) instead of being read from HBM.
@@ -159,16 +62,22 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
   return OGD_OK;
 }
 
+// K2 launch: one wavefront per 64 x 8 output tile, four wavefronts per workgroup (ogd_remap_lds.h).
+constexpr int K2_LX = 16, K2_RPT = 2;
+constexpr int K2_TW = 4 * K2_LX, K2_TH = (64 / K2_LX) * K2_RPT;
+
 template <int C>
-static void launch_remap(int interp, dim3 grid, dim3 block, hipStream_t st, const uint8_t* src, int H,
-                         int W, ptrdiff_t ss, const float* map, int Hd, int Wd, uint8_t* dst,
-                         ptrdiff_t ds) {
+static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
+                         const float* map, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
+  constexpr int LDSW = C == 1 ? 4096 : 8192;  // source window budget per wavefront
+  const int nbx = (Wd + K2_TW - 1) / K2_TW, nby = (Hd + K2_TH - 1) / K2_TH, nb = nbx * nby;
+  const dim3 grid((nb + 3) / 4), block(256);
   if (interp == OGD_INTER_LINEAR)
-    hipLaunchKernelGGL((remap_u8_kernel<C, OGD_INTER_LINEAR>), grid, block, 0, st, src, H, W, ss, map,
-                       Hd, Wd, dst, ds);
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, K2_LX, K2_RPT, LDSW>), grid, block, 0, st,
+                       src, H, W, ss, map, Hd, Wd, dst, ds, nbx, nb);
   else
-    hipLaunchKernelGGL((remap_u8_kernel<C, OGD_INTER_NEAREST>), grid, block, 0, st, src, H, W, ss, map,
-                       Hd, Wd, dst, ds);
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, K2_LX, K2_RPT, LDSW>), grid, block, 0, st,
+                       src, H, W, ss, map, Hd, Wd, dst, ds, nbx, nb);
 }
 
 template <int C>
@@ -197,15 +106,13 @@ int ogd_remap_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_st
   OGD_REQUIRE(d_src && d_map_xy && d_dst, "null pointer");
   OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
   OGD_TRY(ensure_device());
-  dim3 block(RM_TX, RM_TY);
-  dim3 grid((Wd + RM_TX * RM_PX - 1) / (RM_TX * RM_PX), (Hd + RM_TY - 1) / RM_TY);
   hipStream_t st = as_stream(stream);
   switch (C) {
-    case 1: launch_remap<1>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
-    case 3: launch_remap<3>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
-    default: launch_remap<4>(interp, grid, block, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+    case 1: launch_remap<1>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+    case 3: launch_remap<3>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
+    default: launch_remap<4>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
   }
-  return check_launch("remap_u8_kernel");
+  return check_launch("remap_u8_wave_kernel");
 }
 
 int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_stride,

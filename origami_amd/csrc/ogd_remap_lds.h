@@ -1,0 +1,243 @@
+// K2, LDS-tiled remap kernel (ref: origami/core/dewarp.py:612-614, 625-627; arithmetic:
+// ogd_remap_math.h).
+//
+// Every wavefront owns a TW x TH tile of the output (TW = 4 * LX pixels, TH = (64 / LX) * RPT rows; the
+// library launches 64 x 8) and a private slice of LDS, so there is no workgroup barrier anywhere:
+//   1. every lane loads the map of its 4 * RPT pixels (all loads issued before any use) and quantises
+//      it to fixed-point tap coordinates, clamped to the image plus a two-pixel zero border;
+//   2. the wavefront reduces the bounding box of those taps (packed int16 min / max over DPP);
+//   3. that source window is staged in LDS with coalesced dword loads, zero outside the image
+//      (BORDER_CONSTANT 0) — each source byte crosses the vector-memory path once per tile instead of
+//      once per tap, and a pixel whose taps all miss the image blends border zeros (no inside test);
+//   4. the taps are gathered from LDS as aligned dword pairs + v_alignbyte (an unaligned ds_read_u16
+//      is served one lane per cycle), blended with v_dot4_u32_u8 / v_dot2_u32_u16 and stored 4 * C
+//      bytes per lane.
+// The instruction count per pixel, not HBM traffic, is what holds a naive version of this kernel back
+// (measured: DESIGN.md), so everything per pixel is branch-free, 24-bit or packed integer arithmetic.
+// A tile whose window does not fit the LDS pitch / row budget (extreme or erratic maps) is redone
+// from global memory by remap_tile_global; the result is the same bytes either way.
+#pragma once
+#include "ogd_remap_math.h"
+
+namespace ogd {
+
+typedef float rl_f4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t rl_u32u __attribute__((aligned(1)));
+typedef uint16_t rl_u16u __attribute__((aligned(1)));
+typedef short rl_s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ rl_s2 rl_as_s2(int v) { return __builtin_bit_cast(rl_s2, v); }
+__device__ __forceinline__ int rl_as_int(rl_s2 v) { return __builtin_bit_cast(int, v); }
+
+// Packed (int16 x 2) min / max over the wavefront; the result is valid in lane 63.
+template <bool IS_MIN>
+__device__ __forceinline__ int rl_wave_reduce_pk(int v) {
+#define RL_STEP(ctrl)                                                                    \
+  {                                                                                      \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);              \
+    v = rl_as_int(IS_MIN ? __builtin_elementwise_min(rl_as_s2(v), rl_as_s2(o))           \
+                         : __builtin_elementwise_max(rl_as_s2(v), rl_as_s2(o)));         \
+  }
+  RL_STEP(0xB1)   // quad_perm [1,0,3,2]
+  RL_STEP(0x4E)   // quad_perm [2,3,0,1]
+  RL_STEP(0x141)  // row_half_mirror
+  RL_STEP(0x140)  // row_mirror
+  RL_STEP(0x142)  // row_bcast15
+  RL_STEP(0x143)  // row_bcast31
+#undef RL_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).
+template <int C, int INTERP, int LX, int RPT>
+__device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, int H, int W,
+                                               ptrdiff_t ss, const float* __restrict__ map, int Hd,
+                                               int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds, int X,
+                                               int Yb) {
+  constexpr int RW = 64 / LX;
+  for (int r = 0; r < RPT; ++r) {
+    const int Y = Yb + r * RW;
+    if (Y >= Hd) continue;
+    for (int k = 0; k < 4 && X + k < Wd; ++k) {
+      const float* p = map + ((size_t)Y * Wd + X + k) * 2;
+      uint8_t o[C];
+      sample_q<C, INTERP>(src, H, W, ss, quantize<INTERP>(p[0]), quantize<INTERP>(p[1]), o);
+      uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)(X + k) * C;
+      for (int c = 0; c < C; ++c) d[c] = o[c];
+    }
+  }
+}
+
+// Map values of the 4 * RPT pixels a lane owns in tile (bx, by); pixels beyond the right / bottom
+// edge of the output repeat the edge pixel (they are never stored).
+template <int LX, int RPT>
+__device__ __forceinline__ void rl_load_map(const float* __restrict__ map, int Hd, int Wd, int X, int Yb,
+                                            float (&mv)[RPT][8]) {
+  constexpr int RW = 64 / LX;
+  if (X + 4 <= Wd) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + X) * 2;
+      const rl_f4 a = *reinterpret_cast<const rl_f4*>(p), b = *reinterpret_cast<const rl_f4*>(p + 4);
+      mv[r][0] = a.x; mv[r][1] = a.y; mv[r][2] = a.z; mv[r][3] = a.w;
+      mv[r][4] = b.x; mv[r][5] = b.y; mv[r][6] = b.z; mv[r][7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + min(X + k, Wd - 1)) * 2;
+        mv[r][2 * k] = p[0];
+        mv[r][2 * k + 1] = p[1];
+      }
+  }
+}
+
+
+// LDSW: bytes of LDS per wavefront (the source window budget).
+template <int C, int INTERP, int LX, int RPT, int LDSW>
+__global__ __launch_bounds__(256) void remap_u8_wave_kernel(
+    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float* __restrict__ map, int Hd,
+    int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+  constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
+  constexpr int TAPS = LIN ? 2 : 1;
+  constexpr int SHIFT = LIN ? 5 : 0;
+  constexpr int RW = 64 / LX;   // output rows per wave pass
+  constexpr int TH = RW * RPT;  // tile height
+  constexpr int TW = 4 * LX;    // tile width
+  constexpr int PF = ((TW * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
+  constexpr int MAXROWS = LDSW / PF;
+  constexpr int WIN_DW = (PF / 4) * MAXROWS + 2;
+
+  __shared__ uint32_t win_all[4 * WIN_DW];
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= nb) return;  // wave-uniform
+  uint32_t* win = win_all + wave * WIN_DW;
+  const int lx4 = (lane % LX) * 4, ly = lane / LX;
+  const int by = t / nbx, bx = t - by * nbx;
+  const int X = bx * TW + lx4;
+  const int Yb = by * TH + ly;  // row of pass r: Yb + r * RW
+  float mv[RPT][8];
+  rl_load_map<LX, RPT>(map, Hd, Wd, X, Yb, mv);
+
+  // 1. + 2. (see the file comment for the clamp)
+  const float xlo = LIN ? -64.f : -1.f, xhi = LIN ? (float)(W * 32) : (float)W;
+  const float ylo = xlo, yhi = LIN ? (float)(H * 32) : (float)H;
+  int lp[RPT][4];
+  uint32_t wa[RPT][4], wb[RPT][4];
+  int mn = 0x7fff7fff, mx = (int)0x80008000;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ax = LIN ? __fmul_rn(mv[r][2 * k], 32.f) : mv[r][2 * k];
+      const float ay = LIN ? __fmul_rn(mv[r][2 * k + 1], 32.f) : mv[r][2 * k + 1];
+      const int qx = (int)rintf(__builtin_amdgcn_fmed3f(ax, xlo, xhi));
+      const int qy = (int)rintf(__builtin_amdgcn_fmed3f(ay, ylo, yhi));
+      const int cx = qx >> SHIFT, cy = qy >> SHIFT;
+      lp[r][k] = __mul24(cy, PF) + (C == 1 ? cx : __mul24(cx, C));
+      if (LIN) {
+        wa[r][k] = __umul24(qx & 31, 255) + 32;              // (32 - fx) | fx << 8
+        wb[r][k] = __umul24(qy & 31, 64 * 65535) + 64 * 32;  // 64 * ((32 - fy) | fy << 16)
+      }
+      asm volatile("" : "+v"(lp[r][k]));
+      if (LIN) asm volatile("" : "+v"(wa[r][k]), "+v"(wb[r][k]));
+      const int pc = (int)__builtin_amdgcn_perm((uint32_t)cy, (uint32_t)cx, 0x05040100u);  // cx | cy << 16
+      mn = rl_as_int(__builtin_elementwise_min(rl_as_s2(mn), rl_as_s2(pc)));
+      mx = rl_as_int(__builtin_elementwise_max(rl_as_s2(mx), rl_as_s2(pc)));
+    }
+  mn = rl_wave_reduce_pk<true>(mn);
+  mx = rl_wave_reduce_pk<false>(mx);
+  const int mnx = (short)(mn & 0xffff), mny = mn >> 16, mxx = (short)(mx & 0xffff), mxy = mx >> 16;
+  const int x0b = (mnx * C) & ~3;
+  const int wbytes = (mxx + TAPS) * C - x0b;
+  const int nrows = mxy + TAPS - mny;
+  if (wbytes > PF || nrows > MAXROWS) {  // wave-uniform
+    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, map, Hd, Wd, dst, ds, X, Yb);
+    return;
+  }
+
+  // 3. stage: lanes cover (row, dword) pairs, 32 or 64 dwords per window row
+  {
+    const int P4 = (wbytes + 3) >> 2, WB = W * C;
+    const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
+    for (int c = lane & (cw - 1); c < P4; c += cw) {
+      const int xb = x0b + 4 * c;
+      const bool full = xb >= 0 && xb + 4 <= WB;
+      for (int row = lane >> sh; row < nrows; row += rp) {
+        const int y = mny + row;
+        const bool yin = (unsigned)y < (unsigned)H;
+        const uint8_t* prow = src + (ptrdiff_t)y * ss;
+        uint32_t v = 0;
+        if (yin && full) {
+          v = *reinterpret_cast<const rl_u32u*>(prow + xb);
+        } else if (yin) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((unsigned)(xb + j) < (unsigned)WB) v |= (uint32_t)prow[xb + j] << (8 * j);
+        }
+        win[row * (PF / 4) + c] = v;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const uint8_t* wbytes_p = reinterpret_cast<const uint8_t*>(win);
+  const int base = __mul24(mny, PF) + x0b;
+  // 4. gather + blend + store
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int Y = Yb + r * RW;
+    uint32_t o[4 * C];  // result bytes in bits 16..23
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int off = lp[r][k] - base;
+      const uint8_t* p = wbytes_p + off;
+      if (LIN) {
+        uint32_t top[C], bot[C];
+        if (C == 1) {
+          const int i = off >> 2;
+          const uint32_t t2 = __builtin_amdgcn_alignbyte(win[i + 1], win[i], (uint32_t)off);
+          const uint32_t b2 = __builtin_amdgcn_alignbyte(win[i + PF / 4 + 1], win[i + PF / 4], (uint32_t)off);
+          top[0] = __builtin_amdgcn_udot4(t2, wa[r][k], 0u, false);
+          bot[0] = __builtin_amdgcn_udot4(b2, wa[r][k], 0u, false);
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            top[c] = __builtin_amdgcn_udot4((uint32_t)p[c] | ((uint32_t)p[C + c] << 8), wa[r][k], 0u, false);
+            bot[c] = __builtin_amdgcn_udot4((uint32_t)p[PF + c] | ((uint32_t)p[PF + C + c] << 8), wa[r][k], 0u, false);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const uint32_t tb = top[c] | (bot[c] << 16);
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+          o[k * C + c] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, tb), __builtin_bit_cast(us2, wb[r][k]), 64u * 512u, false);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[k * C + c] = (uint32_t)p[c] << 16;
+      }
+    }
+    if (Y < Hd && X < Wd) {
+      uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
+      if (X + 4 <= Wd) {
+#pragma unroll
+        for (int j = 0; j < 4 * C; j += 4) {
+          const uint32_t lo = __builtin_amdgcn_perm(o[j + 1], o[j], 0x0c0c0602u);
+          const uint32_t hi = __builtin_amdgcn_perm(o[j + 3], o[j + 2], 0x06020c0cu);
+          *reinterpret_cast<rl_u32u*>(d + j) = lo | hi;
+        }
+      } else {
+        for (int j = 0; j < (Wd - X) * C; ++j) d[j] = (uint8_t)(o[j] >> 16);
+      }
+    }
+  }
+}
+
+}  // namespace ogd

@@ -1,0 +1,278 @@
+// kbench — kernel laboratory for K2 (remap): times candidate kernels against the library's
+// ogd_remap_u8_dev on one broadsheet page and checks that every candidate is bit-identical to it.
+// Development tool, not part of the product; winners are ported into origami_amd/csrc/ (the tile
+// shape the library launches is K2_LX / K2_RPT in ogd_remap.hip).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/kbench.hip \
+//         -Lorigami_amd/lib -logdewarp -Wl,-rpath,'$ORIGIN/../origami_amd/lib' -o tools/kbench
+//   tools/kbench [W H cell iters]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/ogdewarp.h"
+#include "../origami_amd/csrc/ogd_remap_math.h"
+#include "../origami_amd/csrc/ogd_remap_lds.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+#define OK(x)                                                       \
+  do {                                                              \
+    int s_ = (x);                                                   \
+    if (s_ != 0) {                                                  \
+      fprintf(stderr, "%s: %s\n", #x, ogd_last_error());            \
+      exit(2);                                                      \
+    }                                                               \
+  } while (0)
+
+using namespace ogd;
+
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+template <bool NT>
+__device__ __forceinline__ f4a8 ldmap(const float* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4a8*>(p));
+  return *reinterpret_cast<const f4a8*>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ void st4(uint8_t* p, uint32_t v) {
+  typedef uint32_t u32a1 __attribute__((aligned(1)));
+  if (NT)
+    __builtin_nontemporal_store(v, reinterpret_cast<u32a1*>(p));
+  else
+    *reinterpret_cast<u32a1*>(p) = v;
+}
+
+// logical tile id from the hardware block id: XCD k (= blockIdx % 8 under round-robin dispatch) walks
+// a contiguous band of tiles, so vertically adjacent tiles share that XCD's L2.
+template <bool XCD>
+__device__ __forceinline__ int tile_id(int nb) {
+  if (!XCD) return blockIdx.x;
+  const int per = (nb + 7) >> 3;
+  return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
+// rows variant: a wavefront covers 256 px of ROWS consecutive rows; all map loads are issued first.
+template <int C, int INTERP, int ROWS, bool NT, bool XCD>
+__global__ __launch_bounds__(256) void remap_rows(const uint8_t* __restrict__ src, int H, int W,
+                                                  ptrdiff_t ss, const float* __restrict__ map, int Hd,
+                                                  int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds,
+                                                  int nbx, int nb) {
+  const int t = tile_id<XCD>(nb);
+  if (t >= nb) return;
+  const int by = t / nbx, bx = t - by * nbx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int X = (bx * 64 + lane) * 4;
+  const int Y0 = (by * 4 + wave) * ROWS;
+  if (X >= Wd || Y0 >= Hd) return;
+  if (X + 4 <= Wd) {
+    f4a8 m[ROWS][2];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int Y = min(Y0 + r, Hd - 1);
+      const float* p = map + ((size_t)Y * Wd + X) * 2;
+      m[r][0] = ldmap<NT>(p);
+      m[r][1] = ldmap<NT>(p + 4);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (Y0 + r < Hd) {
+        uint8_t o[4 * C];
+        sample<C, INTERP>(src, H, W, ss, m[r][0].x, m[r][0].y, o);
+        sample<C, INTERP>(src, H, W, ss, m[r][0].z, m[r][0].w, o + C);
+        sample<C, INTERP>(src, H, W, ss, m[r][1].x, m[r][1].y, o + 2 * C);
+        sample<C, INTERP>(src, H, W, ss, m[r][1].z, m[r][1].w, o + 3 * C);
+        uint8_t* d = dst + (ptrdiff_t)(Y0 + r) * ds + (ptrdiff_t)X * C;
+#pragma unroll
+        for (int k = 0; k < 4 * C; k += 4)
+          st4<NT>(d + k, (uint32_t)o[k] | ((uint32_t)o[k + 1] << 8) | ((uint32_t)o[k + 2] << 16) |
+                             ((uint32_t)o[k + 3] << 24));
+      }
+    }
+  } else {
+    for (int r = 0; r < ROWS && Y0 + r < Hd; ++r) {
+      const float* p = map + ((size_t)(Y0 + r) * Wd + X) * 2;
+      uint8_t* d = dst + (ptrdiff_t)(Y0 + r) * ds + (ptrdiff_t)X * C;
+      for (int k = 0; X + k < Wd; ++k) {
+        uint8_t o[C];
+        sample<C, INTERP>(src, H, W, ss, p[2 * k], p[2 * k + 1], o);
+        for (int c = 0; c < C; ++c) d[k * C + c] = o[c];
+      }
+    }
+  }
+}
+
+// streaming ceiling of this access pattern: read the whole map, write one byte per pixel, no gather
+template <int ROWS, bool NT>
+__global__ __launch_bounds__(256) void map_stream(const float* __restrict__ map, int Hd, int Wd,
+                                                  uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+  const int t = blockIdx.x;
+  const int by = t / nbx, bx = t - by * nbx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int X = (bx * 64 + lane) * 4;
+  const int Y0 = (by * 4 + wave) * ROWS;
+  if (X + 4 > Wd || Y0 >= Hd) return;
+  f4a8 m[ROWS][2];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int Y = min(Y0 + r, Hd - 1);
+    const float* p = map + ((size_t)Y * Wd + X) * 2;
+    m[r][0] = ldmap<NT>(p);
+    m[r][1] = ldmap<NT>(p + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+    if (Y0 + r < Hd) {
+      const uint32_t v = (uint32_t)(int)m[r][0].x | ((uint32_t)(int)m[r][0].z << 8) |
+                         ((uint32_t)(int)m[r][1].x << 16) | ((uint32_t)(int)m[r][1].z << 24);
+      st4<NT>(dst + (ptrdiff_t)(Y0 + r) * ds + X, v);
+    }
+}
+
+struct Ctx {
+  int W, H, Wd, Hd, iters;
+  uint8_t *src, *dst, *ref;
+  float* map;
+  std::vector<uint8_t> h_ref, h_out;
+};
+
+template <class F>
+static void run(Ctx& c, const char* name, F launch, bool check = true) {
+  if (const char* only = getenv("KB_ONLY"))
+    if (!strstr(name, only)) return;
+  CK(hipMemset(c.dst, 0xCD, (size_t)c.Hd * c.Wd));
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < c.iters; ++i) launch();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= c.iters;
+  const double bytes = (double)c.Hd * c.Wd * 9 + (double)c.H * c.W;
+  size_t bad = 0;
+  if (check) {
+    CK(hipMemcpy(c.h_out.data(), c.dst, c.h_out.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < c.h_out.size(); ++i) bad += c.h_out[i] != c.h_ref[i];
+  }
+  printf("%-34s %8.4f ms  %7.1f GB/s  %5.1f%% of 8 TB/s  %s\n", name, ms, bytes / ms / 1e6,
+         bytes / ms / 1e6 / 80.0, check ? (bad ? "MISMATCH" : "ok") : "-");
+  if (bad) printf("    %zu bytes differ\n", bad);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  Ctx c;
+  c.W = argc > 1 ? atoi(argv[1]) : 6000;
+  c.H = argc > 2 ? atoi(argv[2]) : 8000;
+  const int cell = argc > 3 ? atoi(argv[3]) : 25;
+  c.iters = argc > 4 ? atoi(argv[4]) : 20;
+  const double A = argc > 5 ? atof(argv[5]) : 0.03;
+  OK(ogd_init(0));
+  const int margin = 1;
+  const int w = (c.W + cell - 1) / cell + 1 + 2 * margin, h = (c.H + cell - 1) / cell + 1 + 2 * margin;
+  c.Wd = w * cell;
+  c.Hd = h * cell;
+  std::vector<float> nodes((size_t)h * w * 2);
+  const double B = A, PI2 = 6.283185307179586;
+  for (int gy = 0; gy < h; ++gy)
+    for (int gx = 0; gx < w; ++gx) {
+      const double X = (gx - margin) * cell, Y = (gy - margin) * cell;
+      const double y = Y + A * c.W * (cos(PI2 * Y / c.H) - cos(PI2 * Y / c.H + X / c.W));
+      const double x = X - B * c.H * (cos(PI2 * X / c.W * 2) - cos(PI2 * X / c.W * 2 + Y / c.H));
+      nodes[((size_t)gy * w + gx) * 2] = (float)x;
+      nodes[((size_t)gy * w + gx) * 2 + 1] = (float)y;
+    }
+  std::vector<uint8_t> page((size_t)c.H * c.W);
+  uint32_t s = 12345;
+  for (auto& v : page) {
+    s = s * 1664525u + 1013904223u;
+    v = (uint8_t)(s >> 24);
+  }
+  float* d_nodes;
+  CK(hipMalloc(&d_nodes, nodes.size() * 4));
+  CK(hipMemcpy(d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&c.map, (size_t)c.Hd * c.Wd * 8));
+  CK(hipMalloc(&c.src, page.size()));
+  CK(hipMemcpy(c.src, page.data(), page.size(), hipMemcpyHostToDevice));
+  CK(hipMalloc(&c.dst, (size_t)c.Hd * c.Wd));
+  OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr));
+  CK(hipDeviceSynchronize());
+  c.h_ref.resize((size_t)c.Hd * c.Wd);
+  c.h_out.resize(c.h_ref.size());
+  printf("page %dx%d, cell %d, dense %dx%d (%.1f MP), warp amplitude %.3f rad\n", c.W, c.H, cell, c.Wd,
+         c.Hd, c.Hd * (double)c.Wd / 1e6, A);
+
+  auto lib = [&] {
+    OK(ogd_remap_u8_dev(c.src, c.H, c.W, 1, c.W, c.map, c.Hd, c.Wd, c.dst, c.Wd, OGD_INTER_LINEAR, nullptr));
+  };
+  lib();
+  CK(hipMemcpy(c.h_ref.data(), c.dst, c.h_ref.size(), hipMemcpyDeviceToHost));
+  run(c, "library ogd_remap_u8_dev", lib);
+
+  const int nbx = (c.Wd + 255) / 256;
+#define ROWS_VARIANT(R, NT, XCD)                                                                        \
+  {                                                                                                     \
+    const int nby = (c.Hd + 4 * R - 1) / (4 * R), nb = nbx * nby;                                       \
+    const int grid = XCD ? ((nb + 7) / 8) * 8 : nb;                                                     \
+    run(c, "rows R=" #R " nt=" #NT " xcd=" #XCD, [&] {                                                  \
+      hipLaunchKernelGGL((remap_rows<1, 1, R, NT, XCD>), dim3(grid), dim3(256), 0, 0, c.src, c.H, c.W,  \
+                         (ptrdiff_t)c.W, c.map, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx, nb);           \
+    });                                                                                                 \
+  }
+  ROWS_VARIANT(1, false, false)
+  ROWS_VARIANT(2, false, false)
+  ROWS_VARIANT(4, false, false)
+  ROWS_VARIANT(8, false, false)
+  ROWS_VARIANT(2, true, false)
+  ROWS_VARIANT(4, true, false)
+  ROWS_VARIANT(8, true, false)
+  ROWS_VARIANT(2, true, true)
+  ROWS_VARIANT(4, true, true)
+  ROWS_VARIANT(8, true, true)
+  ROWS_VARIANT(4, false, true)
+#define WAVE_VARIANT(LX, RPT, LDSW)                                                                     \
+  {                                                                                                     \
+    const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
+    const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
+    run(c, "wave LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                            \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW>), dim3((nb + 3) / 4), dim3(256), 0, \
+                         0, c.src, c.H, c.W, (ptrdiff_t)c.W, c.map, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, \
+                         nbx2, nb);                                                                     \
+    });                                                                                                 \
+  }
+  WAVE_VARIANT(16, 2, 4096)
+  WAVE_VARIANT(16, 2, 8192)
+  WAVE_VARIANT(16, 4, 4096)
+  WAVE_VARIANT(8, 2, 4096)
+  WAVE_VARIANT(8, 4, 4096)
+  WAVE_VARIANT(32, 2, 4096)
+#define STREAM_VARIANT(R, NT)                                                                      \
+  {                                                                                                \
+    const int nby = (c.Hd + 4 * R - 1) / (4 * R), nb = nbx * nby;                                  \
+    run(c, "map-stream only R=" #R " nt=" #NT, [&] {                                               \
+      hipLaunchKernelGGL((map_stream<R, NT>), dim3(nb), dim3(256), 0, 0, c.map, c.Hd, c.Wd, c.dst, \
+                         (ptrdiff_t)c.Wd, nbx, nb);                                                \
+    }, false);                                                                                     \
+  }
+  STREAM_VARIANT(1, false)
+  STREAM_VARIANT(4, false)
+  STREAM_VARIANT(4, true)
+  STREAM_VARIANT(8, true)
+  return 0;
+}
