@@ -1,0 +1,289 @@
+"""Artifacts of a page and their readers / writers — the part of origami/batch/core/io.py the dewarp
+stage touches (same names, file names and skip / overwrite rules).
+
+ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :109-146 (read_contours),
+:227-373 (Reader), :375-387 (Input), :411-416 (AtomicFileWriter), :507-620 (Writer, Output).
+"""
+
+import collections
+import enum
+import json
+import os
+import tempfile
+import zipfile
+from contextlib import contextmanager
+from pathlib import Path
+
+from ...geometry import parse_wkt
+
+
+def find_data_path(page_path):
+	return Path(page_path).with_suffix(".out")
+
+
+class Stage(enum.Enum):
+	WARPED = 0
+	DEWARPED = 1
+	AGGREGATE = 2
+	RELIABLE = 3
+	ANY = -1
+
+	@property
+	def is_dewarped(self):
+		return self.value >= Stage.DEWARPED.value
+
+
+class Artifact(enum.Enum):
+	SEGMENTATION = ("segment.zip",)
+	FLOW = ("flow.zip",)
+	DEWARPING_TRANSFORM = ("dewarp.zip",)
+	RUNTIME = ("runtime.json",)
+	CONTOURS = ("contours.%s.zip", {
+		Stage.WARPED: 0,
+		Stage.DEWARPED: 1,
+		Stage.AGGREGATE: 2,
+		Stage.RELIABLE: 3})
+
+	def __init__(self, filename, stages=None):
+		self._filename = filename
+		self._stages = stages
+
+	def filename(self, stage=None):
+		s = self._filename
+		if self._stages is not None:
+			if stage is None:
+				raise RuntimeError("need to specify stage for loading %s" % self)
+			variant = self._stages.get(stage)
+			if variant is None:
+				raise RuntimeError("%s is not supported for stage %s" % (self, stage))
+			s = s % str(variant)
+		return s
+
+
+class PredictorType(enum.Enum):  # ref: origami/core/predict.py:136-138
+	REGION = 1
+	SEPARATOR = 2
+
+
+Contours = collections.namedtuple("Contours", ["items", "meta"])
+
+
+def read_contours(path, pred_type, open=open):
+	"""[(path parts, Geom)] of one predictor type from a contours zip; ref: io.py:109-146."""
+	items = []
+	pred_meta = dict()
+	with open(path, "rb") as f:
+		with zipfile.ZipFile(f, "r") as zf:
+			meta = json.loads(zf.read("meta.json"))
+			if meta["version"] > 1:
+				predictions = dict((x["name"], x) for x in meta["predictions"])
+			else:
+				predictions = meta
+
+			def wanted(parts):
+				return PredictorType[predictions[parts[0]]["type"]] == pred_type
+
+			for name in zf.namelist():
+				if name.endswith("/meta.json"):
+					parts = tuple(name.split("/"))
+					if wanted(parts):
+						pred_meta[tuple(parts[:-1])] = json.loads(zf.read(name))
+				if not name.endswith(".wkt"):
+					continue
+				parts = tuple(name.rsplit(".", 1)[0].split("/"))
+				if wanted(parts):
+					items.append((parts, parse_wkt(zf.read(name).decode("utf8"))))
+	return Contours(items, pred_meta)
+
+
+class Regions:
+	"""ref: io.py:166-189; the dewarp stage only asks whether a page has any region (by_path)."""
+
+	def __init__(self, path, open=open):
+		self._blocks = dict(read_contours(path, PredictorType.REGION, open=open).items)
+
+	@property
+	def by_path(self):
+		return self._blocks
+
+
+class Reader:
+	def __init__(self, artifacts, stage, page_path, take_any=False, open=open):
+		artifacts = set(artifacts)
+		if Artifact.CONTOURS in artifacts:
+			artifacts.add(Artifact.SEGMENTATION)  # io.py:233-234
+		if stage and stage.is_dewarped and Artifact.CONTOURS in artifacts:
+			artifacts.add(Artifact.DEWARPING_TRANSFORM)
+		self._artifacts = artifacts
+		self._stage = stage
+		self._page_path = Path(page_path)
+		self._data_path = find_data_path(page_path)
+		self._take_any = take_any
+		self._open = open
+		self._cache = {}
+
+	@property
+	def data_path(self):
+		return self._data_path
+
+	@property
+	def paths(self):
+		return [self.path(a) for a in self._artifacts]
+
+	def path(self, artifact):
+		if artifact not in self._artifacts:
+			raise RuntimeError("read on undeclared %s" % artifact)
+		return self._data_path / artifact.filename(self._stage)
+
+	def fix_inconsistent(self):
+		pass
+
+	def is_ready(self):
+		return True if self._take_any else all(p.exists() for p in self.paths)
+
+	@property
+	def missing(self):
+		return [p for p in self.paths if not p.exists()]
+
+	@property
+	def page(self):
+		if "page" not in self._cache:
+			from ...page import Page
+			grid = self.dewarping_transform if self._stage.is_dewarped else None
+			self._cache["page"] = Page(self._page_path, grid)
+		return self._cache["page"]
+
+	@property
+	def regions(self):
+		if "regions" not in self._cache:
+			self._cache["regions"] = Regions(self.path(Artifact.CONTOURS), open=self._open)
+		return self._cache["regions"]
+
+	@property
+	def dewarping_transform(self):
+		if "grid" not in self._cache:
+			from ...dewarp import Grid
+			self._cache["grid"] = Grid.open(self.path(Artifact.DEWARPING_TRANSFORM))
+		return self._cache["grid"]
+
+	@property
+	def flow(self):
+		return zipfile.ZipFile(self.path(Artifact.FLOW), "r")
+
+
+class Input:
+	def __init__(self, *artifacts, stage=None, take_any=False):
+		assert all(isinstance(x, Artifact) for x in artifacts)
+		self._artifacts = set(artifacts)
+		self._stage = stage
+		self._take_any = take_any
+
+	def instantiate(self, processor, file_writer, **kwargs):
+		return Reader(
+			self._artifacts, self._stage, take_any=self._take_any, open=processor.lock_or_open, **kwargs)
+
+
+class AtomicFileWriter:
+	"""Write to a temporary file next to the target, then rename (atomicwrites' behaviour,
+	ref: io.py:411-416)."""
+
+	def __init__(self, overwrite):
+		self._overwrite = overwrite
+
+	@property
+	def overwrite(self):
+		return self._overwrite
+
+	@contextmanager
+	def __call__(self, path, mode):
+		path = Path(path)
+		fd, tmp = tempfile.mkstemp(prefix=".tmp", dir=str(path.parent))
+		try:
+			with os.fdopen(fd, mode) as f:
+				yield f
+			if not self._overwrite and path.exists():
+				raise FileExistsError(str(path))
+			os.replace(tmp, path)
+		except BaseException:
+			try:
+				os.unlink(tmp)
+			except OSError:
+				pass
+			raise
+
+
+class Writer:
+	def __init__(self, artifacts, stage, page_path, processor, file_writer):
+		self._artifacts = artifacts
+		self._stage = stage
+		self._page_path = page_path
+		self._data_path = find_data_path(page_path)
+		self._processor = processor
+		self._write = file_writer
+
+	@property
+	def compression(self):
+		return zipfile.ZIP_DEFLATED
+
+	@property
+	def data_path(self):
+		return self._data_path
+
+	@property
+	def paths(self):
+		return [self.path(a) for a in self._artifacts]
+
+	def path(self, artifact):
+		if artifact not in self._artifacts:
+			raise RuntimeError("write on undeclared %s" % artifact)
+		return self._data_path / artifact.filename(self._stage)
+
+	def fix_inconsistent(self):
+		# a half-written output set is removed so that the page is redone (io.py:533-540)
+		if self._write.overwrite:
+			return
+		e = [p.exists() for p in self.paths]
+		if any(e) and not all(e):
+			for p in self.paths:
+				if p.exists():
+					os.remove(p)
+
+	def is_ready(self):
+		return self._write.overwrite or not any(p.exists() for p in self.paths)
+
+	@property
+	def missing(self):
+		return []
+
+	@contextmanager
+	def write_zip_file(self, artifact):
+		with self._write(self.path(artifact), mode="wb") as f:
+			with zipfile.ZipFile(f, "w", self.compression) as zf:
+				yield zf
+
+	@contextmanager
+	def contours(self, copy_meta_from=None):
+		with self.write_zip_file(Artifact.CONTOURS) as f:
+			if copy_meta_from is not None:
+				path = copy_meta_from.path(Artifact.CONTOURS)
+				with zipfile.ZipFile(path, "r") as zf:
+					f.writestr("meta.json", zf.read("meta.json"))
+					for name in zf.namelist():
+						if name.endswith("/meta.json"):
+							f.writestr(name, zf.read(name))
+			yield f
+
+	@contextmanager
+	def dewarping_transform(self):
+		with self._write(self.path(Artifact.DEWARPING_TRANSFORM), mode="wb") as f:
+			yield f
+
+
+class Output:
+	def __init__(self, *artifacts, stage=None):
+		assert all(isinstance(x, Artifact) for x in artifacts)
+		self._artifacts = set(artifacts)
+		self._stage = stage
+
+	def instantiate(self, **kwargs):
+		return Writer(self._artifacts, self._stage, **kwargs)

@@ -1,0 +1,66 @@
+"""A page image and, given a dewarping grid, its dewarped form (ref: origami/core/page.py:65-117).
+
+`Page(path, grid)` remaps the full page eagerly, as the reference does (page.py:86-88) — on the GPU,
+through Dewarper (K1a + K2 fused)."""
+
+from pathlib import Path
+
+import numpy as np
+import PIL.Image
+
+from .dewarp import Dewarper, Geometry
+
+
+def _is_image(path):
+	try:
+		with PIL.Image.open(str(path)) as im:
+			im.verify()
+		return True
+	except Exception:
+		return False
+
+
+def _find_image_path(path):
+	path = Path(path)
+	if path.exists():
+		return path
+	# do not be picky about the image extension (ref: page.py:70-78)
+	candidates = [
+		c for c in path.parent.glob(path.stem + ".*")
+		if c.name.endswith(".jp2") or (c.is_file() and _is_image(c))]
+	if len(candidates) != 1:
+		raise FileNotFoundError(path)
+	return candidates[0]
+
+
+class Page:
+	def __init__(self, path, dewarping_transform=None):
+		path = _find_image_path(path)
+		self._warped = PIL.Image.open(str(path)).convert("L")
+		if dewarping_transform is not None:
+			self._dewarper = Dewarper(self._warped, dewarping_transform)
+			self._dewarped = self._dewarper.dewarped
+		else:
+			self._dewarper = None
+			self._dewarped = None
+
+	@property
+	def warped(self):
+		return self._warped
+
+	@property
+	def dewarped(self):
+		return self._dewarped
+
+	def size(self, dewarped):
+		return (self._dewarped if dewarped else self._warped).size
+
+	def geometry(self, dewarped):
+		return Geometry(*self.size(dewarped))
+
+	def pixels(self, dewarped):
+		return np.array(self._dewarped if dewarped else self._warped)
+
+	@property
+	def dewarper(self):
+		return self._dewarper

@@ -1,0 +1,144 @@
+"""Batch runtime on CPU: queue building, readiness / skip / overwrite rules, locks, runtime.json and the
+spawned one-worker-per-GPU fan-out (with a stage that does no GPU work).
+
+ref: origami/batch/core/processor.py:368-394, 517-577; io.py:231-236, 261-265, 533-543."""
+
+import json
+import zipfile
+
+import numpy as np
+import pytest
+
+from origami_amd import synth
+from origami_amd.batch.core.io import Artifact, AtomicFileWriter, Stage, find_data_path
+from origami_amd.batch.core.mutex import DatabaseMutex, DummyMutex, FileMutex
+from helpers.fake_stage import FakeDewarpProcessor
+
+
+def make_pages(root, n, prefix="page"):
+	rng = np.random.default_rng(7)
+	paths = []
+	for i in range(n):
+		paths.append(synth.write_page_dir(
+			root, "%s%04d" % (prefix, i), rng, size=(120, 160), n_h=8, n_v=8, n_regions=3, n_separators=1,
+			label_size=(60, 80)))
+	return paths
+
+
+def options(**kw):
+	base = dict(lock_strategy="NONE", processes=1, alive=60, overwrite=False, plain=True)
+	base.update(kw)
+	return base
+
+
+def test_artifact_names():
+	assert Artifact.CONTOURS.filename(Stage.WARPED) == "contours.0.zip"
+	assert Artifact.CONTOURS.filename(Stage.DEWARPED) == "contours.1.zip"
+	assert Artifact.DEWARPING_TRANSFORM.filename() == "dewarp.zip"
+	assert Artifact.FLOW.filename() == "flow.zip" and Artifact.RUNTIME.filename() == "runtime.json"
+	with pytest.raises(RuntimeError):
+		Artifact.CONTOURS.filename()
+	assert find_data_path("/a/b/page.png").name == "page.out"
+	assert Stage.DEWARPED.is_dewarped and not Stage.WARPED.is_dewarped
+
+
+def test_queue_readiness_skip_and_overwrite(tmp_path, capsys):
+	pages = make_pages(tmp_path, 3)
+	(find_data_path(pages[2]) / "segment.zip").unlink()  # CONTOURS implies SEGMENTATION: not ready
+	(tmp_path / "notes.txt").write_text("not an image")
+	proc = FakeDewarpProcessor(options())
+	queued = proc._build_queue(tmp_path)
+	assert [p.name for _, p, _ in queued] == ["page0000.png", "page0001.png"]
+	proc.traverse(tmp_path)
+	for p in pages[:2]:
+		out = find_data_path(p)
+		assert (out / "dewarp.zip").exists() and (out / "contours.1.zip").exists()
+		info = json.loads((out / "runtime.json").read_text())["fake.dewarp"]
+		assert info["status"] == "COMPLETED" and "elapsed" in info
+		with zipfile.ZipFile(out / "contours.1.zip") as zf:  # meta copied first, io.py:569-575
+			assert zf.namelist()[:2] == ["meta.json", "separators/V/meta.json"]
+	assert not (find_data_path(pages[2]) / "dewarp.zip").exists()
+	# outputs exist: nothing is queued again unless --overwrite
+	assert FakeDewarpProcessor(options())._build_queue(tmp_path) == []
+	assert len(FakeDewarpProcessor(options(overwrite=True))._build_queue(tmp_path)) == 2
+	# a half-written output set is removed and the page redone (io.py:533-540)
+	(find_data_path(pages[0]) / "dewarp.zip").unlink()
+	again = FakeDewarpProcessor(options())._build_queue(tmp_path)
+	assert [p.name for _, p, _ in again] == ["page0000.png"]
+	assert not (find_data_path(pages[0]) / "contours.1.zip").exists()
+	# --name filters paths, a .txt file lists pages
+	assert len(FakeDewarpProcessor(options(name="0001", overwrite=True))._build_queue(tmp_path)) == 1
+	listing = tmp_path / "pages.txt"
+	listing.write_text("%s\n\n%s\n" % (pages[0], tmp_path / "missing.png"))
+	assert len(FakeDewarpProcessor(options(overwrite=True))._build_queue(listing)) == 1
+
+
+def test_failure_is_recorded_not_fatal(tmp_path):
+	make_pages(tmp_path, 1, prefix="bad")
+	make_pages(tmp_path, 1, prefix="good")
+	FakeDewarpProcessor(options()).traverse(tmp_path)
+	bad = json.loads((tmp_path / "bad0000.out" / "runtime.json").read_text())["fake.dewarp"]
+	assert bad["status"] == "FAILED" and "synthetic failure" in bad["traceback"]
+	assert not (tmp_path / "bad0000.out" / "dewarp.zip").exists()  # atomic writer leaves nothing behind
+	assert [p.name for p in (tmp_path / "bad0000.out").glob(".tmp*")] == []
+	good = json.loads((tmp_path / "good0000.out" / "runtime.json").read_text())["fake.dewarp"]
+	assert good["status"] == "COMPLETED"
+
+
+def test_atomic_writer(tmp_path):
+	target = tmp_path / "x.bin"
+	with AtomicFileWriter(overwrite=False)(target, "wb") as f:
+		f.write(b"one")
+	assert target.read_bytes() == b"one"
+	with pytest.raises(FileExistsError):
+		with AtomicFileWriter(overwrite=False)(target, "wb") as f:
+			f.write(b"two")
+	with AtomicFileWriter(overwrite=True)(target, "wb") as f:
+		f.write(b"three")
+	assert target.read_bytes() == b"three"
+	assert sorted(p.name for p in tmp_path.iterdir()) == ["x.bin"]
+
+
+def test_mutexes(tmp_path):
+	db = DatabaseMutex(tmp_path / "origami.lock.db", timeout=5)
+	with db.lock("page", ["/a", "/b"]) as locked:
+		assert locked
+		assert not db.try_lock("page", ["/b", "/c"])  # all or nothing
+		assert db.try_lock("other", ["/b"])  # per processor
+	assert db.try_lock("page", ["/a"])  # released
+	db.clear_locks(0)
+	assert db.try_lock("page", ["/a"])
+	f = tmp_path / "page.png"
+	f.write_bytes(b"x")
+	fm = FileMutex()
+	with fm.lock("page", [str(f)]) as a:
+		assert a
+		with fm.lock("page", [str(f)]) as b:
+			assert not b
+	with pytest.raises(RuntimeError):
+		with fm.lock("page", ["/a", "/b"]):
+			pass
+	with DummyMutex().lock("page", ["/a"]) as ok:
+		assert ok
+
+
+@pytest.mark.parametrize("lock", ["NONE", "DB"])
+def test_two_gpu_workers_share_one_queue(tmp_path, lock):
+	"""--gpus 2: two spawned workers, bound to GPUs 0 and 1 before any HIP call, pull chunks from one
+	queue; every page is done exactly once (weak scaling, no data-path collective)."""
+	pages = make_pages(tmp_path, 9)
+	proc = FakeDewarpProcessor(options(gpus=2, devices="0,1", lock_strategy=lock))
+	assert proc.worker_devices(4) == [0, 1, 0, 1]
+	proc.traverse(tmp_path)
+	seen = {}
+	for p in pages:
+		out = find_data_path(p)
+		with zipfile.ZipFile(out / "contours.1.zip") as zf:
+			who = json.loads(zf.read("who.json"))
+		info = json.loads((out / "runtime.json").read_text())["fake.dewarp"]
+		assert info["status"] == "COMPLETED" and info["device"] == int(who["device"])
+		assert who["device"] == str(who["rank"])  # worker r -> device r
+		seen.setdefault(who["rank"], set()).add(who["pid"])
+	assert set(seen) == {0, 1}  # both workers took part (9 pages -> chunks of 2)
+	assert all(len(pids) == 1 for pids in seen.values())
+	assert FakeDewarpProcessor(options())._build_queue(tmp_path) == []

@@ -1,0 +1,84 @@
+"""The dewarp batch stage end to end on the GPU (BASELINE.json configs[0] plumbing, scaled down):
+synthetic page dir -> `dewarp` CLI -> dewarp.zip + contours.1.zip + runtime.json, checked against the
+CPU oracle on the same inputs.  ref: origami/batch/detect/dewarp.py:42-112."""
+
+import io
+import json
+import zipfile
+
+import numpy as np
+import pytest
+from click.testing import CliRunner
+
+from oracle import dewarp as odw
+from origami_amd import geometry, synth
+from origami_amd.batch.detect.dewarp import dewarp
+from origami_amd.dewarp import Grid
+from origami_amd.page import Page
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dewarp_stage_matches_oracle(gpu, tmp_path):
+	rng = np.random.default_rng(11)
+	size = (600, 800)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=120, n_v=160, n_regions=12, n_separators=3,
+		label_size=(320, 427), warp=synth.Warp(size, 0.03, 0.025, 1, 2))
+	out = page_path.with_suffix(".out")
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	assert sorted(p.name for p in out.iterdir()) == [
+		"contours.0.zip", "contours.1.zip", "dewarp.zip", "flow.zip", "runtime.json", "segment.zip"]
+	info = json.loads((out / "runtime.json").read_text())["origami.batch.detect.dewarp"]
+	assert info["status"] == "COMPLETED"
+
+	# dewarp.zip: format and grid values (float grid within 1e-3 px of the oracle's march)
+	with zipfile.ZipFile(out / "dewarp.zip") as zf:
+		assert zf.namelist() == ["data.npy", "meta.json"]
+		meta = json.loads(zf.read("meta.json"))
+		data = np.load(io.BytesIO(zf.read("data.npy")))
+	assert meta["version"] == 1 and meta["cell"] == 25 and meta["shape"] == list(data.shape)
+	assert data.dtype == np.float32
+	with zipfile.ZipFile(out / "flow.zip") as zf:
+		oh, ov = odw.Samples.open(zf, "h"), odw.Samples.open(zf, "v")
+	ogrid = odw.Grid.create(size, oh, ov, grid_res=25)
+	assert data.shape == ogrid.hv.shape
+	assert np.abs(data - ogrid.hv).max() < 1e-3
+
+	# contours.1.zip: same members as contours.0.zip, every ring warped like the oracle does
+	with zipfile.ZipFile(out / "contours.0.zip") as z0, zipfile.ZipFile(out / "contours.1.zip") as z1:
+		assert sorted(z1.namelist()) == sorted(z0.namelist())
+		assert z1.namelist()[0] == "meta.json"
+		assert z1.read("meta.json") == z0.read("meta.json")
+		tf = odw.Grid(data, 25).transformer
+		for name in z0.namelist():
+			if not name.endswith(".wkt"):
+				continue
+			g0 = geometry.parse_wkt(z0.read(name).decode("utf8"))
+			g1 = geometry.parse_wkt(z1.read(name).decode("utf8"))
+			assert g1.geom_type == g0.geom_type and len(g1.rings) == len(g0.rings)
+			for want, got in zip(odw.transform_rings(tf, g0.rings), g1.rings):
+				assert np.abs(want - got).max() < 1e-3
+
+	# a second run skips the page; --overwrite redoes it
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert "0 ready to process" in res.output
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain", "--overwrite"])
+	assert "1 ready to process" in res.output and res.exit_code == 0
+
+	# every later stage opens the page through the saved grid (ref: io.py:275-280, page.py:86-88)
+	page = Page(page_path, Grid.open(out / "dewarp.zip"))
+	h, w = data.shape[:2]
+	assert page.dewarped.size == (w * 25, h * 25)
+	want = odw.dewarped(np.array(page.warped), odw.Grid(data, 25))
+	np.testing.assert_array_equal(np.array(page.dewarped), want)
+
+
+def test_page_without_regions_is_skipped_silently(gpu, tmp_path):
+	rng = np.random.default_rng(12)
+	page_path = synth.write_page_dir(tmp_path, "empty", rng, size=(300, 400), n_h=20, n_v=20, n_regions=0, n_separators=1, label_size=(160, 213))
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"])
+	assert res.exit_code == 0
+	out = page_path.with_suffix(".out")
+	assert not (out / "dewarp.zip").exists() and not (out / "contours.1.zip").exists()  # ref: dewarp.py:64-67
