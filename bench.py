@@ -58,6 +58,8 @@ def parse_args():
 	ap.add_argument("--pages", type=int, default=64, help="pages per batch and GPU")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
+	ap.add_argument("--harness-selftest", action="store_true",
+		help="CPU / gloo run of the N-rank timing harness with a sleeping step (tests/test_multi.py)")
 	return ap.parse_args()
 
 
@@ -177,6 +179,58 @@ def cpu_baseline(wl, threads, budget_s=12.0):
 			n, spent, t_pix, threads, wl["polys"][0]["nrings"], t_pts))
 
 
+def timed_steps(step, steps, warmup, sync, dist, world, device, between=None):
+	"""The timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier +
+	device synchronisation on both sides; returns the MAX over ranks of the elapsed seconds."""
+	import torch
+
+	def barrier():
+		sync()
+		if world > 1:
+			dist.barrier()
+			sync()
+
+	for _ in range(warmup):
+		step(False)
+	barrier()
+	if between is not None:
+		between()
+		barrier()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		step(True)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+	return elapsed
+
+
+def harness_selftest(args, rank, world):
+	"""Ranks sleep (rank + 1) * 10 ms per step: the reported time must be the slowest rank's."""
+	import torch
+	import torch.distributed as dist
+	if world > 1:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		dist.init_process_group("gloo", rank=rank, world_size=world)
+	calls = []
+
+	def step(timed):
+		calls.append(timed)
+		time.sleep(0.01 * (rank + 1))
+
+	elapsed = timed_steps(step, args.steps, args.warmup, lambda: None, dist, world, torch.device("cpu"))
+	assert calls == [False] * args.warmup + [True] * args.steps
+	if rank == 0:
+		print(json.dumps({"selftest": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+			"ms_per_step": round(elapsed / args.steps * 1e3, 3), "value": world * args.steps / elapsed}), flush=True)
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
 def main():
 	args = parse_args()
 	rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +238,8 @@ def main():
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if world != args.gpus and world > 1:
 		raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+	if args.harness_selftest:
+		return harness_selftest(args, rank, world)
 
 	import torch
 	import torch.distributed as dist
@@ -203,27 +259,10 @@ def main():
 	wl = build_workload(torch, _shim, dev, args.pages, rank)
 	stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-	def barrier():
-		torch.cuda.synchronize()
-		if world > 1:
-			dist.barrier()
-			torch.cuda.synchronize()
-
-	for _ in range(args.warmup):
-		run_step(torch, lib, check, wl, stream)
-	barrier()
-	verify(torch, wl)
 	events = []
-	barrier()
-	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		run_step(torch, lib, check, wl, stream, events)
-	barrier()
-	elapsed = time.perf_counter() - t0
-	if world > 1:
-		t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-		elapsed = float(t.item())
+	elapsed = timed_steps(
+		lambda timed: run_step(torch, lib, check, wl, stream, events if timed else None),
+		args.steps, args.warmup, torch.cuda.synchronize, dist, world, dev, between=lambda: verify(torch, wl))
 
 	Hd, Wd = wl["Hd"], wl["Wd"]
 	W, H = PAGE
