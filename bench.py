@@ -8,8 +8,8 @@ One "step" = one pass of the GPU path over one batch of synthetic pages resident
   K1a  ogd_grid_fill_dev        node grid -> dense sampling grid (8075 x 6075 x 2 f32)
   K2   ogd_remap_u8_dev         page -> dewarped page through that grid (the roofline kernel)
   K3   ogd_tri_eval_ragged_dev  every contour ring through the forward transformer
-All launches go through the C ABI (ctypes) on torch's current stream; torch only owns device
-memory, events and (N > 1) the barrier.  Pages are independent: with N > 1 every rank dewarps its own
+All launches go through the C ABI (ctypes): K1a / K2 on torch's current stream, K3 (which depends on
+neither) on a second stream; torch only owns device memory, streams, events and (N > 1) the barrier.  Pages are independent: with N > 1 every rank dewarps its own
 batch (weak scaling, no collective on the data path).
 
 The host-side grid construction (marching the node grid, Qhull) is set-up, as it is in the reference,
@@ -108,7 +108,7 @@ def build_workload(torch, shim, dev, n_pages, rank):
 	return dict(base=base, pages=pages, warps=warps, polys=polys, dense=dense, outs=outs, Hd=Hd, Wd=Wd, h=h, w=w)
 
 
-def run_step(torch, lib, check, wl, stream, events=None):
+def run_step(torch, lib, check, wl, stream, events=None, side_stream=None):
 	W, H = PAGE
 	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
 	n_pages = wl["pages"].shape[0]
@@ -126,9 +126,10 @@ def run_step(torch, lib, check, wl, stream, events=None):
 		if events is not None:
 			e1.record()
 			events.append((e0, e1))
+		# K3 depends on nothing K1a / K2 produce: it runs on its own stream and fills the gaps
 		check(lib.ogd_tri_eval_ragged_dev(
 			wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
-			poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), stream))
+			poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream or stream))
 
 
 def verify(torch, wl):
@@ -258,10 +259,12 @@ def main():
 
 	wl = build_workload(torch, _shim, dev, args.pages, rank)
 	stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+	side = torch.cuda.Stream()  # contour warps (K3) overlap the pixel kernels; both are synchronised by the barrier
+	side_stream = ctypes.c_void_p(side.cuda_stream)
 
 	events = []
 	elapsed = timed_steps(
-		lambda timed: run_step(torch, lib, check, wl, stream, events if timed else None),
+		lambda timed: run_step(torch, lib, check, wl, stream, events if timed else None, side_stream),
 		args.steps, args.warmup, torch.cuda.synchronize, dist, world, dev, between=lambda: verify(torch, wl))
 
 	Hd, Wd = wl["Hd"], wl["Wd"]

@@ -60,6 +60,11 @@ int ogd_stream_sync(void* stream);
 int ogd_grid_fill(const float* nodes, int h, int w, int s, float sx, float sy, float* out);
 int ogd_grid_fill_dev(const float* d_nodes, int h, int w, int s, float sx, float sy,
                       float* d_out, void* stream);
+/* Rows y0 .. y0+nrows-1 of the same dense grid, written to d_out rows 0 .. nrows-1 (a band buffer).  A
+ * caller that alternates band fills with ogd_remap_u8_dev on the band (map = d_out, Hd = nrows, dst
+ * advanced by y0 rows) keeps the map in the 256 MB Infinity Cache instead of streaming it through HBM. */
+int ogd_grid_fill_rows_dev(const float* d_nodes, int h, int w, int s, float sx, float sy,
+                           int y0, int nrows, float* d_out, void* stream);
 /* Same values sampled at dense pixels (ox*step, oy*step) only; out: [ceil(h*s/step)][ceil(w*s/step)][2].
  * ref: origami/core/dewarp.py:557-559 (points("full")[::r, ::r]) without materialising the map. */
 int ogd_grid_points_strided(const float* nodes, int h, int w, int s, int step, float* out);

@@ -44,6 +44,8 @@ SIGNATURES = {
 	"ogd_stream_sync": (c_int, [c_void_p]),
 	"ogd_grid_fill": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
 	"ogd_grid_fill_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+	"ogd_grid_fill_rows_dev": (c_int, [
+		c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
 	"ogd_grid_points_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 	"ogd_remap_u8": (c_int, [
 		c_void_p, c_int, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_void_p, c_ssize_t, c_int]),

@@ -14,20 +14,19 @@ namespace ogd {
 constexpr int GF_THREADS = 256;
 constexpr int GF_ROWS = 16;
 
-struct __attribute__((aligned(8))) float4_a8 {
-  float x, y, z, w;
-};
+typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 __global__ __launch_bounds__(GF_THREADS) void grid_fill_kernel(
     const float2* __restrict__ nodes, int h, int w, double inv_s, float scx, float scy,
-    float2* __restrict__ out, int Hd, int Wd) {
+    float2* __restrict__ out, int ybeg, int yend, int Wd) {
+  // dense rows [ybeg, yend) go to out rows 0 .. yend - ybeg - 1
   const int X = (blockIdx.x * GF_THREADS + threadIdx.x) * 2;
   if (X >= Wd) return;
   const bool pair = (X + 1 < Wd);
   const Tap tx0 = tap_x(X, inv_s, w);
   const Tap tx1 = tap_x(pair ? X + 1 : X, inv_s, w);
-  const int Y0 = blockIdx.y * GF_ROWS;
-  const int Y1 = min(Y0 + GF_ROWS, Hd);
+  const int Y0 = ybeg + blockIdx.y * GF_ROWS;
+  const int Y1 = min(Y0 + GF_ROWS, yend);
 
   int cur0 = -1, cur1 = -1;
   float2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f};  // horizontally lerped node row i0 for column X, X+1
@@ -51,9 +50,9 @@ __global__ __launch_bounds__(GF_THREADS) void grid_fill_kernel(
     v.y = __fmul_rn(lerp2(ta0.y, ty.w0, tb0.y, ty.w1), scy);
     v.z = __fmul_rn(lerp2(ta1.x, ty.w0, tb1.x, ty.w1), scx);
     v.w = __fmul_rn(lerp2(ta1.y, ty.w0, tb1.y, ty.w1), scy);
-    float2* o = out + (size_t)Y * Wd + X;
+    float2* o = out + (size_t)(Y - ybeg) * Wd + X;
     if (pair)
-      *reinterpret_cast<float4_a8*>(o) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<float4_a8*>(o));
     else
       *o = make_float2(v.x, v.y);
   }
@@ -122,18 +121,26 @@ using namespace ogd;
 
 extern "C" {
 
-int ogd_grid_fill_dev(const float* d_nodes, int h, int w, int s, float sx, float sy, float* d_out,
-                      void* stream) {
+int ogd_grid_fill_rows_dev(const float* d_nodes, int h, int w, int s, float sx, float sy, int y0,
+                           int nrows, float* d_out, void* stream) {
   OGD_TRY(check_nodes(h, w, s));
   OGD_REQUIRE(d_nodes && d_out, "null pointer");
-  OGD_TRY(ensure_device());
   const int Hd = h * s, Wd = w * s;
-  dim3 grid((Wd + 2 * GF_THREADS - 1) / (2 * GF_THREADS), (Hd + GF_ROWS - 1) / GF_ROWS);
+  OGD_REQUIRE(y0 >= 0 && nrows >= 0 && (int64_t)y0 + nrows <= Hd, "rows [%d, %d + %d) outside the dense grid (%d rows)", y0, y0, nrows, Hd);
+  if (nrows == 0) return OGD_OK;
+  OGD_TRY(ensure_device());
+  dim3 grid((Wd + 2 * GF_THREADS - 1) / (2 * GF_THREADS), (nrows + GF_ROWS - 1) / GF_ROWS);
   OGD_REQUIRE(grid.y <= 65535u, "dense grid too tall");
   hipLaunchKernelGGL(grid_fill_kernel, grid, dim3(GF_THREADS), 0, as_stream(stream),
                      reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy,
-                     reinterpret_cast<float2*>(d_out), Hd, Wd);
+                     reinterpret_cast<float2*>(d_out), y0, y0 + nrows, Wd);
   return check_launch("grid_fill_kernel");
+}
+
+int ogd_grid_fill_dev(const float* d_nodes, int h, int w, int s, float sx, float sy, float* d_out,
+                      void* stream) {
+  OGD_TRY(check_nodes(h, w, s));
+  return ogd_grid_fill_rows_dev(d_nodes, h, w, s, sx, sy, 0, h * s, d_out, stream);
 }
 
 int ogd_grid_fill(const float* nodes, int h, int w, int s, float sx, float sy, float* out) {

@@ -225,6 +225,23 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(c.h_ref.data(), c.dst, c.h_ref.size(), hipMemcpyDeviceToHost));
   run(c, "library ogd_remap_u8_dev", lib);
 
+  // K1a -> K2 page pipeline, whole map vs row bands through one band buffer (Infinity Cache residency)
+  for (int nbands : {1, 2, 3, 4, 6, 8, 12, 16, 32}) {
+    char name[64];
+    snprintf(name, sizeof name, "pipeline K1a+K2, %d band(s)", nbands);
+    const int rows = ((c.Hd + nbands - 1) / nbands + 7) / 8 * 8;
+    run(c, name, [&] {
+      for (int y0 = 0; y0 < c.Hd; y0 += rows) {
+        const int n = std::min(rows, c.Hd - y0);
+        OK(ogd_grid_fill_rows_dev(d_nodes, h, w, cell, 1.f, 1.f, y0, n, c.map, nullptr));
+        OK(ogd_remap_u8_dev(c.src, c.H, c.W, 1, c.W, c.map, n, c.Wd, c.dst + (size_t)y0 * c.Wd, c.Wd,
+                            OGD_INTER_LINEAR, nullptr));
+      }
+    });
+  }
+  OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr));
+  CK(hipDeviceSynchronize());
+
   const int nbx = (c.Wd + 255) / 256;
 #define ROWS_VARIANT(R, NT, XCD)                                                                        \
   {                                                                                                     \
