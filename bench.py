@@ -34,7 +34,7 @@ CELL = 25
 N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is ~2 s each)
 N_POLYGONS = 400
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096>"
+K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
 TRAFFIC_JSON = ROOT / "profiles" / "r01" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh)
 
 
@@ -130,6 +130,38 @@ def run_step(torch, lib, check, wl, stream, events=None, side_stream=None):
 		check(lib.ogd_tri_eval_ragged_dev(
 			wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
 			poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream or stream))
+
+
+def fused_pass(torch, lib, check, wl, stream, side_stream, repeats=2):
+	"""Secondary figure, outside the timed steps: the same batch through the fused kernel the product's
+	Dewarper uses (ogd_dewarp_u8_dev: the dense map never exists) + K3.  Returns (MP/s, ms per page)."""
+	W, H = PAGE
+	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
+	n_pages = wl["pages"].shape[0]
+	# parity of the fused path against the unfused outputs of the timed steps (page 0)
+	want = wl["outs"][0].clone()
+
+	def one_pass():
+		for p in range(n_pages):
+			wp = wl["warps"][p % len(wl["warps"])]
+			poly = wl["polys"][p]
+			check(lib.ogd_dewarp_u8_dev(
+				wl["pages"][p].data_ptr(), H, W, 1, W, wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0,
+				wl["outs"][p].data_ptr(), Wd, 1, stream))
+			check(lib.ogd_tri_eval_ragged_dev(
+				wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
+				poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream))
+
+	one_pass()
+	torch.cuda.synchronize()
+	if not torch.equal(wl["outs"][0], want):
+		raise SystemExit("bench: fused path differs from the unfused path")
+	t0 = time.perf_counter()
+	for _ in range(repeats):
+		one_pass()
+	torch.cuda.synchronize()
+	dt = (time.perf_counter() - t0) / repeats
+	return n_pages * Hd * Wd / 1e6 / dt, dt / n_pages * 1e3
 
 
 def verify(torch, wl):
@@ -267,6 +299,12 @@ def main():
 		lambda timed: run_step(torch, lib, check, wl, stream, events if timed else None, side_stream),
 		args.steps, args.warmup, torch.cuda.synchronize, dist, world, dev, between=lambda: verify(torch, wl))
 
+	fused_mps, fused_ms = fused_pass(torch, lib, check, wl, stream, side_stream)
+	if world > 1:
+		t = torch.tensor([fused_mps], dtype=torch.float64, device=dev)
+		dist.all_reduce(t, op=dist.ReduceOp.SUM)
+		fused_mps = float(t.item())
+
 	Hd, Wd = wl["Hd"], wl["Wd"]
 	W, H = PAGE
 	mp_per_step = args.pages * Hd * Wd / 1e6
@@ -295,6 +333,10 @@ def main():
 				"pages_per_gpu": args.pages,
 				"distinct_warps": len(wl["warps"]),
 				"parallelism": "page-sharded x%d, no collective" % world,
+			},
+			"fused_path": {
+				"what": "same batch through ogd_dewarp_u8_dev (K1a fused into K2, no dense map; what Dewarper.dewarped runs) + K3; measured after the timed steps, not part of value",
+				"value": round(fused_mps, 1), "unit": "MP/s", "ms_per_page": round(fused_ms, 4),
 			},
 			"roofline": {
 				"kernel": K2_KERNEL,

@@ -13,46 +13,13 @@
 //
 // HBM traffic per output pixel: 8 B of map read + C B written + ~C B of source.  K2 proper (materialised
 // map) is the LDS-tiled remap_u8_wave_kernel of ogd_remap_lds.h; the fused kernel below recomputes the
-// map from the node grid and gathers from global memory.
+// map from the node grid inside the same kernel (MapNodes).
 #include "ogd_common.h"
 #include "ogd_resize_math.h"
 #include "ogd_remap_math.h"
 #include "ogd_remap_lds.h"
 
 namespace ogd {
-
-constexpr int RM_TX = 64;  // threads along x (one wavefront = one row segment)
-constexpr int RM_TY = 4;   // rows per block
-constexpr int RM_PX = 4;   // pixels per thread
-
-// Fused variant: the map value of every output pixel is recomputed from the node grid (K1a
-// arithmetic, bit-identical to grid_fill_kernel) instead of being read from HBM.
-template <int C, int INTERP>
-__global__ __launch_bounds__(RM_TX* RM_TY) void dewarp_u8_kernel(
-    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float2* __restrict__ nodes,
-    int h, int w, double inv_s, float scx, float scy, int Hd, int Wd, uint8_t* __restrict__ dst,
-    ptrdiff_t ds) {
-  const int X = (blockIdx.x * RM_TX + threadIdx.x) * RM_PX;
-  const int Y = blockIdx.y * RM_TY + threadIdx.y;
-  if (X >= Wd || Y >= Hd) return;
-  const Tap ty = tap_y(Y, inv_s, h);
-  uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
-  uint8_t o[RM_PX * C];
-  const int n = min(RM_PX, Wd - X);
-#pragma unroll
-  for (int k = 0; k < RM_PX; ++k) {
-    if (k < n) {
-      const Tap tx = tap_x(X + k, inv_s, w);
-      const float2 v = dense_at(nodes, w, tx, ty);
-      sample<C, INTERP>(src, H, W, ss, __fmul_rn(v.x, scx), __fmul_rn(v.y, scy), o + k * C);
-    }
-  }
-  if (n == RM_PX) {
-    store_bytes<RM_PX * C>(d, o);
-  } else {
-    for (int k = 0; k < n * C; ++k) d[k] = o[k];
-  }
-}
 
 static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) {
   OGD_REQUIRE(H >= 1 && W >= 1, "%s: empty image (%dx%d)", what, W, H);
@@ -66,30 +33,28 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
 constexpr int K2_LX = 16, K2_RPT = 2;
 constexpr int K2_TW = 4 * K2_LX, K2_TH = (64 / K2_LX) * K2_RPT;
 
-template <int C>
+template <int C, class MapSrc>
 static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
-                         const float* map, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
+                         const MapSrc& ms, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
   constexpr int LDSW = C == 1 ? 4096 : 8192;  // source window budget per wavefront
   const int nbx = (Wd + K2_TW - 1) / K2_TW, nby = (Hd + K2_TH - 1) / K2_TH, nb = nbx * nby;
   const dim3 grid((nb + 3) / 4), block(256);
   if (interp == OGD_INTER_LINEAR)
-    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, K2_LX, K2_RPT, LDSW>), grid, block, 0, st,
-                       src, H, W, ss, map, Hd, Wd, dst, ds, nbx, nb);
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, K2_LX, K2_RPT, LDSW, MapSrc>), grid, block,
+                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
   else
-    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, K2_LX, K2_RPT, LDSW>), grid, block, 0, st,
-                       src, H, W, ss, map, Hd, Wd, dst, ds, nbx, nb);
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, K2_LX, K2_RPT, LDSW, MapSrc>), grid, block,
+                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
 }
 
-template <int C>
-static void launch_dewarp(int interp, dim3 grid, dim3 block, hipStream_t st, const uint8_t* src, int H,
-                          int W, ptrdiff_t ss, const float2* nodes, int h, int w, double inv_s,
-                          float scx, float scy, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
-  if (interp == OGD_INTER_LINEAR)
-    hipLaunchKernelGGL((dewarp_u8_kernel<C, OGD_INTER_LINEAR>), grid, block, 0, st, src, H, W, ss, nodes,
-                       h, w, inv_s, scx, scy, Hd, Wd, dst, ds);
-  else
-    hipLaunchKernelGGL((dewarp_u8_kernel<C, OGD_INTER_NEAREST>), grid, block, 0, st, src, H, W, ss,
-                       nodes, h, w, inv_s, scx, scy, Hd, Wd, dst, ds);
+template <class MapSrc>
+static void launch_remap_c(int C, int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
+                           const MapSrc& ms, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
+  switch (C) {
+    case 1: launch_remap<1>(interp, st, src, H, W, ss, ms, Hd, Wd, dst, ds); break;
+    case 3: launch_remap<3>(interp, st, src, H, W, ss, ms, Hd, Wd, dst, ds); break;
+    default: launch_remap<4>(interp, st, src, H, W, ss, ms, Hd, Wd, dst, ds); break;
+  }
 }
 
 }  // namespace ogd
@@ -106,12 +71,8 @@ int ogd_remap_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_st
   OGD_REQUIRE(d_src && d_map_xy && d_dst, "null pointer");
   OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
   OGD_TRY(ensure_device());
-  hipStream_t st = as_stream(stream);
-  switch (C) {
-    case 1: launch_remap<1>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
-    case 3: launch_remap<3>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
-    default: launch_remap<4>(interp, st, d_src, H, W, src_stride, d_map_xy, Hd, Wd, d_dst, dst_stride); break;
-  }
+  const MapGlobal ms{d_map_xy, Hd, Wd};
+  launch_remap_c(C, interp, as_stream(stream), d_src, H, W, src_stride, ms, Hd, Wd, d_dst, dst_stride);
   return check_launch("remap_u8_wave_kernel");
 }
 
@@ -126,17 +87,9 @@ int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_s
   OGD_REQUIRE(d_src && d_nodes && d_dst, "null pointer");
   OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
   OGD_TRY(ensure_device());
-  dim3 block(RM_TX, RM_TY);
-  dim3 grid((Wd + RM_TX * RM_PX - 1) / (RM_TX * RM_PX), (Hd + RM_TY - 1) / RM_TY);
-  hipStream_t st = as_stream(stream);
-  const float2* nodes = reinterpret_cast<const float2*>(d_nodes);
-  const double inv_s = 1.0 / (double)s;
-  switch (C) {
-    case 1: launch_dewarp<1>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
-    case 3: launch_dewarp<3>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
-    default: launch_dewarp<4>(interp, grid, block, st, d_src, H, W, src_stride, nodes, h, w, inv_s, sx, sy, Hd, Wd, d_dst, dst_stride); break;
-  }
-  return check_launch("dewarp_u8_kernel");
+  const MapNodes ms{reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy, Hd, Wd};
+  launch_remap_c(C, interp, as_stream(stream), d_src, H, W, src_stride, ms, Hd, Wd, d_dst, dst_stride);
+  return check_launch("remap_u8_wave_kernel<MapNodes>");
 }
 
 int ogd_remap_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, const float* map_xy,

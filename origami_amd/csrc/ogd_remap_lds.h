@@ -1,5 +1,6 @@
 // K2, LDS-tiled remap kernel (ref: origami/core/dewarp.py:612-614, 625-627; arithmetic:
-// ogd_remap_math.h).
+// ogd_remap_math.h) — with the map read from memory (MapGlobal) or recomputed from the node grid
+// (MapNodes: the fused K1a + K2 of Dewarper.dewarped / dewarp_image, ref: dewarp.py:608-627).
 //
 // Every wavefront owns a TW x TH tile of the output (TW = 4 * LX pixels, TH = (64 / LX) * RPT rows; the
 // library launches 64 x 8) and a private slice of LDS, so there is no workgroup barrier anywhere:
@@ -18,6 +19,7 @@
 // from global memory by remap_tile_global; the result is the same bytes either way.
 #pragma once
 #include "ogd_remap_math.h"
+#include "ogd_resize_math.h"
 
 namespace ogd {
 
@@ -25,6 +27,17 @@ typedef float rl_f4 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t rl_u32u __attribute__((aligned(1)));
 typedef uint16_t rl_u16u __attribute__((aligned(1)));
 typedef short rl_s2 __attribute__((ext_vector_type(2)));
+
+// Pointers that arrive inside a by-value struct lose their address space (hipcc then emits flat loads);
+// these casts give it back.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RL_GLOBAL __attribute__((address_space(1)))
+#else
+#define RL_GLOBAL  // the host pass only parses the kernels
+#endif
+typedef const float RL_GLOBAL* rl_gf;
+typedef const rl_f4 RL_GLOBAL* rl_gf4;
+typedef const float2 RL_GLOBAL* rl_gf2;
 
 __device__ __forceinline__ rl_s2 rl_as_s2(int v) { return __builtin_bit_cast(rl_s2, v); }
 __device__ __forceinline__ int rl_as_int(rl_s2 v) { return __builtin_bit_cast(int, v); }
@@ -48,58 +61,141 @@ __device__ __forceinline__ int rl_wave_reduce_pk(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---- where the map comes from ------------------------------------------------------------------------
+// A map source yields the (x, y) sampling position of output pixels: `load` for the 4 * RPT pixels a
+// lane owns in its tile (pixels beyond the right / bottom edge of the output repeat the edge pixel; they
+// are never stored), `at` for one pixel (slow path).
+
+// K2 proper: the dense map materialised in memory ([Hd][Wd] float2).
+struct MapGlobal {
+  const float* __restrict__ map;
+  int Hd, Wd;
+
+  __device__ __forceinline__ float2 at(int X, int Y) const {
+    const rl_gf p = (rl_gf)map + ((size_t)Y * Wd + X) * 2;
+    return make_float2(p[0], p[1]);
+  }
+
+  template <int LX, int RPT>
+  __device__ __forceinline__ void load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int) const {
+    constexpr int RW = 64 / LX;
+    if (X + 4 <= Wd) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const rl_gf p = (rl_gf)map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + X) * 2;
+        const rl_f4 a = *(rl_gf4)p, b = *(rl_gf4)(p + 4);
+        mv[r][0] = a.x; mv[r][1] = a.y; mv[r][2] = a.z; mv[r][3] = a.w;
+        mv[r][4] = b.x; mv[r][5] = b.y; mv[r][6] = b.z; mv[r][7] = b.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 v = at(min(X + k, Wd - 1), min(Yb + r * RW, Hd - 1));
+          mv[r][2 * k] = v.x;
+          mv[r][2 * k + 1] = v.y;
+        }
+    }
+  }
+};
+
+// Fused K1a + K2: the map value is recomputed from the node grid (ogd_resize_math.h, bit-identical
+// to grid_fill_kernel) and scaled like dewarp_image does; the dense map never exists.
+struct MapNodes {
+  const float2* __restrict__ nodes;
+  int h, w;
+  double inv_s;
+  float scx, scy;
+  int Hd, Wd;
+
+  __device__ __forceinline__ float2 at(int X, int Y) const {
+    const float2 v = dense_at((rl_gf2)nodes, w, tap_x(X, inv_s, w), tap_y(Y, inv_s, h));
+    return make_float2(__fmul_rn(v.x, scx), __fmul_rn(v.y, scy));
+  }
+
+  // `lds` is the wavefront's window slice (free until the window is staged): the node sub-grid the
+  // tile touches is staged there first, so every pixel reads its four nodes from LDS instead of
+  // issuing four global loads.  (X0, Y0) is the tile origin.
+  template <int LX, int RPT>
+  __device__ __forceinline__ void load(int X, int Yb, float (&mv)[RPT][8], uint32_t* lds, int lds_dwords,
+                                       int lane, int X0, int Y0) const {
+    constexpr int RW = 64 / LX, TW = 4 * LX, TH = RW * RPT;
+    const int jlo = tap_x(X0, inv_s, w).i0, jhi = tap_x(min(X0 + TW - 1, Wd - 1), inv_s, w).i1;
+    const int ilo = tap_y(Y0, inv_s, h).i0, ihi = tap_y(min(Y0 + TH - 1, Hd - 1), inv_s, h).i1;
+    const int nc = jhi - jlo + 1, nn = nc * (ihi - ilo + 1);
+    const bool in_lds = 2 * nn <= lds_dwords;  // wave-uniform
+    float2* ln = reinterpret_cast<float2*>(lds);
+    if (in_lds) {
+      for (int idx = lane; idx < nn; idx += 64) {
+        const int r = idx / nc, c = idx - r * nc;
+        ln[idx] = ((rl_gf2)nodes)[(size_t)(ilo + r) * w + jlo + c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    Tap tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tx[k] = tap_x(min(X + k, Wd - 1), inv_s, w);
+    if (in_lds) {  // two bodies, so that the LDS one keeps its address space (ds_read, not flat loads)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tx[k].i0 -= jlo;
+        tx[k].i1 -= jlo;
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        Tap ty = tap_y(min(Yb + r * RW, Hd - 1), inv_s, h);
+        ty.i0 -= ilo;
+        ty.i1 -= ilo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 v = dense_at(ln, nc, tx[k], ty);
+          mv[r][2 * k] = __fmul_rn(v.x, scx);
+          mv[r][2 * k + 1] = __fmul_rn(v.y, scy);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const Tap ty = tap_y(min(Yb + r * RW, Hd - 1), inv_s, h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 v = dense_at((rl_gf2)nodes, w, tx[k], ty);
+          mv[r][2 * k] = __fmul_rn(v.x, scx);
+          mv[r][2 * k + 1] = __fmul_rn(v.y, scy);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the slice is re-used for the source window next
+  }
+};
+
 // Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).
-template <int C, int INTERP, int LX, int RPT>
+template <int C, int INTERP, int LX, int RPT, class MapSrc>
 __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, int H, int W,
-                                               ptrdiff_t ss, const float* __restrict__ map, int Hd,
-                                               int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds, int X,
-                                               int Yb) {
+                                               ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
+                                               uint8_t* __restrict__ dst, ptrdiff_t ds, int X, int Yb) {
   constexpr int RW = 64 / LX;
   for (int r = 0; r < RPT; ++r) {
     const int Y = Yb + r * RW;
     if (Y >= Hd) continue;
     for (int k = 0; k < 4 && X + k < Wd; ++k) {
-      const float* p = map + ((size_t)Y * Wd + X + k) * 2;
+      const float2 m = ms.at(X + k, Y);
       uint8_t o[C];
-      sample_q<C, INTERP>(src, H, W, ss, quantize<INTERP>(p[0]), quantize<INTERP>(p[1]), o);
+      sample_q<C, INTERP>(src, H, W, ss, quantize<INTERP>(m.x), quantize<INTERP>(m.y), o);
       uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)(X + k) * C;
       for (int c = 0; c < C; ++c) d[c] = o[c];
     }
   }
 }
 
-// Map values of the 4 * RPT pixels a lane owns in tile (bx, by); pixels beyond the right / bottom
-// edge of the output repeat the edge pixel (they are never stored).
-template <int LX, int RPT>
-__device__ __forceinline__ void rl_load_map(const float* __restrict__ map, int Hd, int Wd, int X, int Yb,
-                                            float (&mv)[RPT][8]) {
-  constexpr int RW = 64 / LX;
-  if (X + 4 <= Wd) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + X) * 2;
-      const rl_f4 a = *reinterpret_cast<const rl_f4*>(p), b = *reinterpret_cast<const rl_f4*>(p + 4);
-      mv[r][0] = a.x; mv[r][1] = a.y; mv[r][2] = a.z; mv[r][3] = a.w;
-      mv[r][4] = b.x; mv[r][5] = b.y; mv[r][6] = b.z; mv[r][7] = b.w;
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + min(X + k, Wd - 1)) * 2;
-        mv[r][2 * k] = p[0];
-        mv[r][2 * k + 1] = p[1];
-      }
-  }
-}
-
-
 // LDSW: bytes of LDS per wavefront (the source window budget).
-template <int C, int INTERP, int LX, int RPT, int LDSW>
+template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
 __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
-    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const float* __restrict__ map, int Hd,
-    int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
+    uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
   constexpr int TAPS = LIN ? 2 : 1;
   constexpr int SHIFT = LIN ? 5 : 0;
@@ -121,7 +217,7 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   const int X = bx * TW + lx4;
   const int Yb = by * TH + ly;  // row of pass r: Yb + r * RW
   float mv[RPT][8];
-  rl_load_map<LX, RPT>(map, Hd, Wd, X, Yb, mv);
+  ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH);
 
   // 1. + 2. (see the file comment for the clamp)
   const float xlo = LIN ? -64.f : -1.f, xhi = LIN ? (float)(W * 32) : (float)W;
@@ -156,7 +252,7 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   const int wbytes = (mxx + TAPS) * C - x0b;
   const int nrows = mxy + TAPS - mny;
   if (wbytes > PF || nrows > MAXROWS) {  // wave-uniform
-    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, map, Hd, Wd, dst, ds, X, Yb);
+    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb);
     return;
   }
 

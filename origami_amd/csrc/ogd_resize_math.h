@@ -55,10 +55,10 @@ __device__ __forceinline__ float lerp2(float a, float wa, float b, float wb) {
 }
 
 // Dense map value at (X, Y); nodes is [h][w] float2.
-__device__ __forceinline__ float2 dense_at(const float2* __restrict__ nodes, int w, const Tap& tx,
-                                           const Tap& ty) {
-  const float2* r0 = nodes + (size_t)ty.i0 * w;
-  const float2* r1 = nodes + (size_t)ty.i1 * w;
+template <class NodePtr>
+__device__ __forceinline__ float2 dense_at(NodePtr nodes, int w, const Tap& tx, const Tap& ty) {
+  const NodePtr r0 = nodes + (size_t)ty.i0 * w;
+  const NodePtr r1 = nodes + (size_t)ty.i1 * w;
   float2 a = r0[tx.i0], b = r0[tx.i1], c = r1[tx.i0], d = r1[tx.i1];
   float t0x = lerp2(a.x, tx.w0, b.x, tx.w1), t0y = lerp2(a.y, tx.w0, b.y, tx.w1);
   float t1x = lerp2(c.x, tx.w0, d.x, tx.w1), t1y = lerp2(c.y, tx.w0, d.y, tx.w1);

@@ -224,6 +224,9 @@ int main(int argc, char** argv) {
   lib();
   CK(hipMemcpy(c.h_ref.data(), c.dst, c.h_ref.size(), hipMemcpyDeviceToHost));
   run(c, "library ogd_remap_u8_dev", lib);
+  run(c, "library ogd_dewarp_u8_dev (fused)", [&] {
+    OK(ogd_dewarp_u8_dev(c.src, c.H, c.W, 1, c.W, d_nodes, h, w, cell, 1.f, 1.f, c.dst, c.Wd, OGD_INTER_LINEAR, nullptr));
+  });
 
   // K1a -> K2 page pipeline, whole map vs row bands through one band buffer (Infinity Cache residency)
   for (int nbands : {1, 2, 3, 4, 6, 8, 12, 16, 32}) {
@@ -268,9 +271,9 @@ int main(int argc, char** argv) {
     const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
     const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
     run(c, "wave LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                            \
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW>), dim3((nb + 3) / 4), dim3(256), 0, \
-                         0, c.src, c.H, c.W, (ptrdiff_t)c.W, c.map, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, \
-                         nbx2, nb);                                                                     \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobal>), dim3((nb + 3) / 4),    \
+                         dim3(256), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd},  \
+                         c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                                                                    \
     });                                                                                                 \
   }
   WAVE_VARIANT(16, 2, 4096)
