@@ -140,6 +140,33 @@ __global__ __launch_bounds__(256) void map_stream(const float* __restrict__ map,
     }
 }
 
+// streaming ceiling of K2's own tile shape: the map loads of remap_u8_wave_kernel, one dword out per lane-row
+template <int LX, int RPT>
+__global__ __launch_bounds__(256) void map_stream_tile(const float* __restrict__ map, int Hd, int Wd,
+                                                       uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+  constexpr int RW = 64 / LX, TH = RW * RPT, TW = 4 * LX;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= nb) return;
+  const int by = t / nbx, bx = t - by * nbx;
+  const int X = bx * TW + (lane % LX) * 4, Yb = by * TH + lane / LX;
+  if (X + 4 > Wd) return;
+  f4a8 m[RPT][2];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + X) * 2;
+    m[r][0] = ldmap<false>(p);
+    m[r][1] = ldmap<false>(p + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+    if (Yb + r * RW < Hd) {
+      const uint32_t v = (uint32_t)(int)m[r][0].x | ((uint32_t)(int)m[r][0].z << 8) |
+                         ((uint32_t)(int)m[r][1].x << 16) | ((uint32_t)(int)m[r][1].z << 24);
+      st4<false>(dst + (ptrdiff_t)(Yb + r * RW) * ds + X, v);
+    }
+}
+
 struct Ctx {
   int W, H, Wd, Hd, iters;
   uint8_t *src, *dst, *ref;
@@ -282,6 +309,22 @@ int main(int argc, char** argv) {
   WAVE_VARIANT(8, 2, 4096)
   WAVE_VARIANT(8, 4, 4096)
   WAVE_VARIANT(32, 2, 4096)
+#define STREAM_TILE(LX, RPT)                                                                           \
+  {                                                                                                     \
+    const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
+    const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
+    run(c, "map-stream tile LX=" #LX " RPT=" #RPT, [&] {                                                \
+      hipLaunchKernelGGL((map_stream_tile<LX, RPT>), dim3((nb + 3) / 4), dim3(256), 0, 0, c.map, c.Hd,  \
+                         c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                                       \
+    }, false);                                                                                          \
+  }
+  STREAM_TILE(16, 2)
+  STREAM_TILE(16, 4)
+  STREAM_TILE(32, 2)
+  STREAM_TILE(32, 4)
+  STREAM_TILE(64, 1)
+  STREAM_TILE(64, 2)
+  STREAM_TILE(64, 4)
 #define STREAM_VARIANT(R, NT)                                                                      \
   {                                                                                                \
     const int nby = (c.Hd + 4 * R - 1) / (4 * R), nb = nbx * nby;                                  \
