@@ -45,6 +45,9 @@ int ogd_version(void);
 int ogd_device_count(int* count);
 /* Bind the calling thread to `device` (-1: OGD_DEVICE env, else 0) and create its context. */
 int ogd_init(int device);
+/* The host-buffer entry points keep the device blocks they used in a per-thread cache; this frees the
+ * calling thread's idle ones (bytes freed are returned through freed_bytes if it is not NULL). */
+int ogd_trim(size_t* freed_bytes);
 int ogd_dev_alloc(void** dptr, size_t bytes);
 int ogd_dev_free(void* dptr);
 int ogd_memcpy_h2d(void* dptr, const void* hptr, size_t bytes, void* stream);

@@ -37,6 +37,7 @@ SIGNATURES = {
 	"ogd_version": (c_int, []),
 	"ogd_device_count": (c_int, [POINTER(c_int)]),
 	"ogd_init": (c_int, [c_int]),
+	"ogd_trim": (c_int, [POINTER(c_size_t)]),
 	"ogd_dev_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
 	"ogd_dev_free": (c_int, [c_void_p]),
 	"ogd_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

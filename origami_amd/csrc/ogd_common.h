@@ -37,24 +37,32 @@ int ensure_device();
     if (_s != OGD_OK) return _s; \
   } while (0)
 
-// A device buffer owned for the duration of one host-buffer entry point.
+// Device memory of the host-buffer entry points comes from a per-thread cache of blocks (grow-only,
+// best fit): a worker that dewarps page after page pays hipMalloc / hipFree once, not per call.
+// ogd_trim() gives the calling thread's idle blocks back.
+void* pool_take(size_t bytes);  // nullptr on failure (error already set)
+void pool_give(void* p);
+
+// A device buffer held for the duration of one host-buffer entry point.
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) pool_give(p);
   }
   int alloc(size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return fail(OGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    }
-    return OGD_OK;
+    p = pool_take(bytes ? bytes : 16);
+    return p ? OGD_OK : OGD_ERR_NOMEM;
   }
   template <class T>
   T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// Host <-> device copies of images with a row stride: one linear copy when rows are packed.
+inline hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                            size_t rows, hipMemcpyKind kind) {
+  if (dpitch == width && spitch == width) return hipMemcpy(dst, src, width * rows, kind);
+  return hipMemcpy2D(dst, dpitch, src, spitch, width, rows, kind);
+}
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

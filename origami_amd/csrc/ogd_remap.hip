@@ -105,11 +105,11 @@ int ogd_remap_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, 
   OGD_TRY(dmap.alloc(mb));
   OGD_TRY(ddst.alloc(drow * Hd));
   // the last source row may be shorter than the stride in the caller's buffer
-  OGD_HIP(hipMemcpy2D(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
+  OGD_HIP(copy_rows(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
   OGD_HIP(hipMemcpy(dmap.p, map_xy, mb, hipMemcpyHostToDevice));
   OGD_TRY(ogd_remap_u8_dev(dsrc.as<uint8_t>(), H, W, C, src_stride, dmap.as<float>(), Hd, Wd,
                            ddst.as<uint8_t>(), (ptrdiff_t)drow, interp, nullptr));
-  OGD_HIP(hipMemcpy2D(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
+  OGD_HIP(copy_rows(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
   return OGD_OK;
 }
 
@@ -129,11 +129,11 @@ int ogd_dewarp_u8(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride,
   OGD_TRY(dsrc.alloc(sb));
   OGD_TRY(dn.alloc(nb));
   OGD_TRY(ddst.alloc(drow * Hd));
-  OGD_HIP(hipMemcpy2D(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
+  OGD_HIP(copy_rows(dsrc.p, src_stride, src, src_stride, (size_t)W * C, H, hipMemcpyHostToDevice));
   OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
   OGD_TRY(ogd_dewarp_u8_dev(dsrc.as<uint8_t>(), H, W, C, src_stride, dn.as<float>(), h, w, s, sx, sy,
                             ddst.as<uint8_t>(), (ptrdiff_t)drow, interp, nullptr));
-  OGD_HIP(hipMemcpy2D(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
+  OGD_HIP(copy_rows(dst, dst_stride, ddst.p, drow, drow, Hd, hipMemcpyDeviceToHost));
   return OGD_OK;
 }
 

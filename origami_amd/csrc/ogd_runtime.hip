@@ -4,6 +4,7 @@
 #include "ogd_common.h"
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace ogd {
 
@@ -61,6 +62,82 @@ int ensure_device() {
   return bind_device(-1);
 }
 
+// ---- per-thread device block cache ---------------------------------------------------------------
+struct PoolBlock {
+  void* p;
+  size_t bytes;
+  int device;
+  bool busy;
+};
+
+struct Pool {
+  std::vector<PoolBlock> blocks;
+  ~Pool() {
+    // thread exit: hand idle blocks back unless the HIP runtime is already gone
+    for (auto& b : blocks)
+      if (!b.busy && b.p) (void)hipFree(b.p);
+  }
+};
+static thread_local Pool g_pool;
+
+void* pool_take(size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  PoolBlock* best = nullptr;
+  for (auto& b : g_pool.blocks)
+    if (!b.busy && b.device == dev && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+  // a block more than 4x too large stays free for a larger request
+  if (best && best->bytes <= 4 * bytes + (1u << 20)) {
+    best->busy = true;
+    return best->p;
+  }
+  const size_t rounded = (bytes + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);  // 2 MiB granules
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, rounded);
+  if (e != hipSuccess) {
+    // out of memory: drop this thread's idle blocks and try once more
+    for (auto& b : g_pool.blocks)
+      if (!b.busy && b.p) {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+      }
+    e = hipMalloc(&p, rounded);
+  }
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(e));
+    return nullptr;
+  }
+  for (auto& b : g_pool.blocks)
+    if (!b.p) {
+      b = PoolBlock{p, rounded, dev, true};
+      return p;
+    }
+  g_pool.blocks.push_back(PoolBlock{p, rounded, dev, true});
+  return p;
+}
+
+void pool_give(void* p) {
+  for (auto& b : g_pool.blocks)
+    if (b.p == p) {
+      b.busy = false;
+      return;
+    }
+  (void)hipFree(p);  // not ours (cannot happen through DevBuf)
+}
+
+static size_t pool_trim() {
+  size_t freed = 0;
+  for (auto& b : g_pool.blocks)
+    if (!b.busy && b.p) {
+      (void)hipFree(b.p);
+      freed += b.bytes;
+      b.p = nullptr;
+      b.bytes = 0;
+    }
+  return freed;
+}
+
 }  // namespace ogd
 
 using namespace ogd;
@@ -84,6 +161,12 @@ int ogd_device_count(int* count) {
 }
 
 int ogd_init(int device) { return bind_device(device); }
+
+int ogd_trim(size_t* freed_bytes) {
+  const size_t n = pool_trim();
+  if (freed_bytes) *freed_bytes = n;
+  return OGD_OK;
+}
 
 int ogd_dev_alloc(void** dptr, size_t bytes) {
   OGD_REQUIRE(dptr != nullptr, "dptr is NULL");
