@@ -134,6 +134,26 @@ int ogd_tri_rasterize_dev(const ogd_tri* inner, const ogd_tri* extra, const doub
 int ogd_grid_sample_bilinear(const float* nodes, int h, int w, int s,
                              const double* q_yx, int64_t nq, double* out_xy);
 
+/* ---- device-resident pages and per-line images ---------------------------------
+ * ref: origami/core/page.py:82-88 (every later stage opens the page and dewarps it), origami/core/block.py:
+ * 223-259 (Line.warped_grid + Line.dewarped_image: one small cv2.remap per text line, thousands per page),
+ * origami/batch/core/lines.py:121-149 (LineExtractor).  A page is uploaded once; all lines of the page
+ * are extracted by ONE launch. */
+typedef struct ogd_page ogd_page;
+int ogd_page_create(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, ogd_page** out);
+int ogd_page_destroy(ogd_page* page);
+/* Dewarper.dewarped / dewarp_image of a resident page (fused K1a + K2), ref: dewarp.py:608-627. */
+int ogd_page_dewarp_u8(const ogd_page* page, const float* nodes, int h, int w, int s, float sx, float sy,
+                       uint8_t* dst, ptrdiff_t dst_stride, int interp);
+/* lines: [n][6] float64 = p0.x, p0.y, right.x, right.y, up.x, up.y in dewarped pixels; line l yields a
+ * ysteps[l] x xsteps[l] x C image (rows already flipped as block.py:257 does) at out + offsets[l];
+ * offsets: [n + 1] byte offsets.  Sample (i, j) sits at p0 + linspace(0, up, ysteps)[i] +
+ * linspace(0, right, xsteps)[j], goes through the inverse map (fp64 bilinear over the dense grid, cast to
+ * float32) and is read from the warped page like cv2.remap does. */
+int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, int s,
+                       const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n,
+                       int interp, uint8_t* out, const int64_t* offsets);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,13 +315,17 @@ class Grid:
 			self._transformer = Transformer(self.points_full()[::r, ::r], r)
 		return self._transformer
 
-	def inverse(self, pts_xy):
-		# dewarp.py:561-576
+	def inverse_yx(self, pts_yx):
+		# dewarp.py:561-572
 		grid = self.points_full()
 		interp = scipy.interpolate.RegularGridInterpolator(
 			(np.arange(grid.shape[0]), np.arange(grid.shape[1])), grid, method="linear",
 			bounds_error=False, fill_value=None)
-		return interp(np.flip(pts_xy, axis=-1))
+		return interp(pts_yx)
+
+	def inverse(self, pts_xy):
+		# dewarp.py:574-576
+		return self.inverse_yx(np.flip(pts_xy, axis=-1))
 
 	def save(self, path):
 		# dewarp.py:546-553

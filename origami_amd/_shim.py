@@ -74,6 +74,13 @@ SIGNATURES = {
 		c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int, c_int, c_void_p, c_int64,
 		c_int64, c_int, c_void_p]),
 	"ogd_grid_sample_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+	"ogd_page_create": (c_int, [c_void_p, c_int, c_int, c_int, c_ssize_t, POINTER(c_void_p)]),
+	"ogd_page_destroy": (c_int, [c_void_p]),
+	"ogd_page_dewarp_u8": (c_int, [
+		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_ssize_t, c_int]),
+	"ogd_line_images_u8": (c_int, [
+		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+		c_void_p]),
 }
 
 _lib = None
@@ -198,6 +205,69 @@ def dewarp_u8(src, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
 		_ptr(src), H, W, C, src.strides[0], _ptr(nodes), h, w, int(cell), float(sx), float(sy),
 		_ptr(dst), dst.strides[0], int(interpolation)))
 	return dst[:, :, 0] if squeeze else dst
+
+
+# ---- resident pages, per-line images (N1) ---------------------------------------------------------
+
+class DevicePage:
+	"""A uint8 page kept in device memory (ogd_page): upload once, dewarp / cut lines many times."""
+
+	def __init__(self, pixels):
+		src, self._squeeze = _image(pixels)
+		self.shape = src.shape
+		h = c_void_p()
+		check(load().ogd_page_create(
+			_ptr(src), src.shape[0], src.shape[1], src.shape[2], src.strides[0], ctypes.byref(h)))
+		self._h = h
+
+	def close(self):
+		if self._h is not None and _lib is not None:
+			_lib.ogd_page_destroy(self._h)
+		self._h = None
+
+	__del__ = close
+
+	def __enter__(self):
+		return self
+
+	def __exit__(self, *exc):
+		self.close()
+
+	@property
+	def handle(self):
+		if self._h is None:
+			raise ValueError("page is closed")
+		return self._h
+
+	def dewarp(self, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
+		nodes = _c(nodes, np.float32)
+		h, w = nodes.shape[:2]
+		dst = np.empty((h * cell, w * cell, self.shape[2]), dtype=np.uint8)
+		check(load().ogd_page_dewarp_u8(
+			self.handle, _ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(dst), dst.strides[0],
+			int(interpolation)))
+		return dst[:, :, 0] if self._squeeze else dst
+
+	def line_images(self, nodes, cell, lines, xsteps, ysteps, interpolation=INTER_LINEAR):
+		"""lines: (n, 6) float64 rows p0.x p0.y right.x right.y up.x up.y -> list of n uint8 images."""
+		nodes = _c(nodes, np.float32)
+		h, w = nodes.shape[:2]
+		lines = _c(lines, np.float64).reshape(-1, 6)
+		n = len(lines)
+		xs = _c(np.broadcast_to(xsteps, (n,)), np.int32)
+		ys = _c(np.broadcast_to(ysteps, (n,)), np.int32)
+		C = self.shape[2]
+		offsets = np.zeros(n + 1, dtype=np.int64)
+		np.cumsum(xs.astype(np.int64) * ys * C, out=offsets[1:])
+		out = np.empty(int(offsets[-1]), dtype=np.uint8)
+		check(load().ogd_line_images_u8(
+			self.handle, _ptr(nodes), h, w, int(cell), _ptr(lines), _ptr(xs), _ptr(ys), n,
+			int(interpolation), _ptr(out), _ptr(offsets)))
+		images = []
+		for k in range(n):
+			im = out[offsets[k]:offsets[k + 1]].reshape(ys[k], xs[k], C)
+			images.append(im[:, :, 0] if self._squeeze else im)
+		return images
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------

@@ -69,43 +69,12 @@ __global__ __launch_bounds__(256) void grid_points_strided_kernel(
   out[(size_t)oy * ow + ox] = dense_at(nodes, w, tx, ty);
 }
 
-// Inverse point map: bilinear (fp64) sample of the dense grid at fractional (y, x), extrapolating
-// linearly from the edge cell.  Follows scipy RegularGridInterpolator over (arange(Hd), arange(Wd)):
-//   i = searchsorted(grid, x, 'left') - 1, clamped to [0, n-2]; t = (x - i) / 1
-//   value = sum over (i, j) in [(i0,j0), (i0,j1), (i1,j0), (i1,j1)] of v * ((1 * wy) * wx)
-__device__ __forceinline__ int rgi_index(double x, int n) {
-  int i = (int)ceil(x) - 1;  // searchsorted(left) on integers: #{k : k < x} - 1
-  if (!(x == x)) i = n - 1;  // NaN sorts last
-  i = max(i, 0);
-  i = min(i, n - 2);
-  return i;
-}
-
 __global__ __launch_bounds__(256) void grid_sample_bilinear_kernel(
     const float2* __restrict__ nodes, int h, int w, int s, double inv_s, const double2* __restrict__ q_yx,
     int64_t nq, double2* __restrict__ out_xy) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nq) return;
-  const int Hd = h * s, Wd = w * s;
-  const double y = q_yx[k].x, x = q_yx[k].y;
-  const int iy = rgi_index(y, Hd), ix = rgi_index(x, Wd);
-  const double ty = y - (double)iy, tx = x - (double)ix;
-  const Tap ax0 = tap_x(ix, inv_s, w), ax1 = tap_x(ix + 1, inv_s, w);
-  const Tap ay0 = tap_y(iy, inv_s, h), ay1 = tap_y(iy + 1, inv_s, h);
-  const float2 v00 = dense_at(nodes, w, ax0, ay0), v01 = dense_at(nodes, w, ax1, ay0);
-  const float2 v10 = dense_at(nodes, w, ax0, ay1), v11 = dense_at(nodes, w, ax1, ay1);
-  const double w00 = __dmul_rn(1.0 - ty, 1.0 - tx), w01 = __dmul_rn(1.0 - ty, tx);
-  const double w10 = __dmul_rn(ty, 1.0 - tx), w11 = __dmul_rn(ty, tx);
-  double ox = 0.0, oy = 0.0;
-  ox = __dadd_rn(ox, __dmul_rn((double)v00.x, w00));
-  oy = __dadd_rn(oy, __dmul_rn((double)v00.y, w00));
-  ox = __dadd_rn(ox, __dmul_rn((double)v01.x, w01));
-  oy = __dadd_rn(oy, __dmul_rn((double)v01.y, w01));
-  ox = __dadd_rn(ox, __dmul_rn((double)v10.x, w10));
-  oy = __dadd_rn(oy, __dmul_rn((double)v10.y, w10));
-  ox = __dadd_rn(ox, __dmul_rn((double)v11.x, w11));
-  oy = __dadd_rn(oy, __dmul_rn((double)v11.y, w11));
-  out_xy[k] = make_double2(ox, oy);
+  out_xy[k] = grid_inverse_at(nodes, h, w, s, inv_s, q_yx[k].x, q_yx[k].y);
 }
 
 static int check_nodes(int h, int w, int s) {

@@ -8,6 +8,7 @@ from pathlib import Path
 import numpy as np
 import PIL.Image
 
+from . import _shim
 from .dewarp import Dewarper, Geometry
 
 
@@ -37,6 +38,7 @@ class Page:
 	def __init__(self, path, dewarping_transform=None):
 		path = _find_image_path(path)
 		self._warped = PIL.Image.open(str(path)).convert("L")
+		self._device_page = None
 		if dewarping_transform is not None:
 			self._dewarper = Dewarper(self._warped, dewarping_transform)
 			self._dewarped = self._dewarper.dewarped
@@ -64,3 +66,10 @@ class Page:
 	@property
 	def dewarper(self):
 		return self._dewarper
+
+	@property
+	def device_page(self):
+		"""The warped page resident in device memory; line images are cut from it (block.py:255)."""
+		if self._device_page is None:
+			self._device_page = _shim.DevicePage(np.array(self._warped))
+		return self._device_page

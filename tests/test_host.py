@@ -143,3 +143,47 @@ def test_synthetic_page_dir_layout(tmp_path):
 		assert sum(n.startswith("regions/TEXT/") for n in names) == 5
 		g = geometry.parse_wkt(zf.read("regions/TEXT/0.wkt").decode("utf8"))
 		assert g.geom_type == "Polygon" and g.area > 0
+
+
+# ---- N1: line lattices (host side) ------------------------------------------------------------------
+
+def test_oracle_line_lattice_identity_grid():
+	"""On an identity grid the warped lattice IS the dewarped lattice, and the image is the flipped crop."""
+	from oracle import block as oblock
+	from oracle import dewarp as odw
+	s, h, w = 10, 8, 12
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float32)
+	# cv2.resize pixel-centre alignment: nodes at (k + 0.5) * s - 0.5 give map(x, y) = (x, y) inside
+	nodes = np.stack([(gx + 0.5) * s - 0.5, (gy + 0.5) * s - 0.5], axis=-1).astype(np.float32)
+	grid = odw.Grid(nodes, s)
+	wg = oblock.warped_grid(grid, (20, 50), (40, 0), (0, -16), xsteps=41, ysteps=17)
+	assert wg.shape == (17, 41, 2) and wg.dtype == np.float32
+	np.testing.assert_allclose(wg[0, :, 0], 20 + np.arange(41), atol=1e-4)
+	np.testing.assert_allclose(wg[:, 0, 1], 50 - np.arange(17), atol=1e-4)
+	rng = np.random.default_rng(0)
+	page = rng.integers(0, 256, size=(h * s, w * s), dtype=np.uint8)
+	im = oblock.dewarped_image(page, grid, (20, 50), (40, 0), (0, -16), target_height=17)
+	assert im.shape == (17, 41)
+	np.testing.assert_array_equal(im, page[34:51, 20:61])
+	# steps chosen from the rough lattice: ceil(|dx| = 40) columns (41 if float32 noise lands above 40)
+	hh, ww, _ = oblock.warped_grid(grid, (20, 50), (40, 0), (0, -16)).shape
+	assert hh in (16, 17) and ww in (40, 41)
+
+
+def test_line_position_with_column():
+	from origami_amd import block as blk
+	ln = blk.Line(None, (10.0, 100.0), (200.0, 4.0), (0.0, -30.0))
+	p0, right, up, xres = ln._position(1, None)
+	assert p0.tolist() == [10.0, 100.0] and right.tolist() == [200.0, 4.0] and xres == 1
+	p0, right, up, xres = ln._position(1, (60.0, 110.0))
+	np.testing.assert_allclose(p0, [60.0, 101.0])
+	np.testing.assert_allclose(right, [50.0, 1.0])
+	assert xres == pytest.approx(0.25)
+	p0, right, up, xres = ln._position(2, (None, 110.0))
+	np.testing.assert_allclose(p0, [10.0, 100.0])
+	np.testing.assert_allclose(right, [100.0, 2.0])
+	assert xres == pytest.approx(1.0)
+	# a column outside the baseline leaves that end alone (intersect_segments default)
+	p0, right, up, xres = ln._position(1, (-50.0, 400.0))
+	np.testing.assert_allclose(p0, [10.0, 100.0])
+	np.testing.assert_allclose(right, [200.0, 4.0])
