@@ -1,8 +1,9 @@
 """Artifacts of a page and their readers / writers — the part of origami/batch/core/io.py the dewarp
-stage touches (same names, file names and skip / overwrite rules).
+and line-export stages touch (same names, file names and skip / overwrite rules).
 
-ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :109-146 (read_contours),
-:227-373 (Reader), :375-387 (Input), :411-416 (AtomicFileWriter), :507-620 (Writer, Output).
+ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :92-97 (DebuggingArtifact),
+:109-146 (read_contours), :166-224 (Regions, Lines), :227-373 (Reader), :375-387 (Input),
+:411-416 (AtomicFileWriter), :507-620 (Writer, Output).
 """
 
 import collections
@@ -37,11 +38,15 @@ class Artifact(enum.Enum):
 	SEGMENTATION = ("segment.zip",)
 	FLOW = ("flow.zip",)
 	DEWARPING_TRANSFORM = ("dewarp.zip",)
+	TABLES = ("tables.json",)
 	RUNTIME = ("runtime.json",)
 	CONTOURS = ("contours.%s.zip", {
 		Stage.WARPED: 0,
 		Stage.DEWARPED: 1,
 		Stage.AGGREGATE: 2,
+		Stage.RELIABLE: 3})
+	LINES = ("lines.%s.zip", {
+		Stage.WARPED: 0,
 		Stage.RELIABLE: 3})
 
 	def __init__(self, filename, stages=None):
@@ -58,6 +63,14 @@ class Artifact(enum.Enum):
 				raise RuntimeError("%s is not supported for stage %s" % (self, stage))
 			s = s % str(variant)
 		return s
+
+
+class DebuggingArtifact:  # ref: io.py:92-97
+	def __init__(self, filename):
+		self._filename = filename
+
+	def filename(self, stage=None):
+		return self._filename
 
 
 class PredictorType(enum.Enum):  # ref: origami/core/predict.py:136-138
@@ -97,19 +110,59 @@ def read_contours(path, pred_type, open=open):
 
 
 class Regions:
-	"""ref: io.py:166-189; the dewarp stage only asks whether a page has any region (by_path)."""
+	"""ref: io.py:166-189.  `page` may be a zero-argument callable (see Block)."""
 
-	def __init__(self, path, open=open):
-		self._blocks = dict(read_contours(path, PredictorType.REGION, open=open).items)
+	def __init__(self, path, page, stage, open=open):
+		from ...block import Block
+		self._blocks = dict(
+			(parts, Block(page, polygon, stage))
+			for parts, polygon in read_contours(path, PredictorType.REGION, open=open).items)
 
 	@property
 	def by_path(self):
 		return self._blocks
 
 
+class Lines:
+	"""ref: io.py:192-224 — one JSON per line (Line.info) under the path of its block."""
+
+	def __init__(self, path, regions, stage=Stage.WARPED, open=open):
+		from ...block import Line
+		blocks = regions.by_path
+		assert all(block.stage == stage for block in blocks.values())
+		self._meta = None
+		lines = dict()
+		with open(path, "rb") as lf:
+			with zipfile.ZipFile(lf, "r") as zf:
+				for name in zf.namelist():
+					if name == "meta.json":
+						self._meta = json.loads(zf.read(name))
+						continue
+					if not name.endswith(".json"):
+						raise RuntimeError("illegal file %s in %s." % (name, path))
+					parts = tuple(name.rsplit(".", 1)[0].split("/"))
+					block = blocks[tuple(parts[:3])]
+					lines[parts] = Line(block, **json.loads(zf.read(name)))
+		self._lines = lines
+
+	@property
+	def meta(self):
+		return self._meta
+
+	@property
+	def min_confidence(self):
+		return self.meta.get("min_confidence", 0.5)
+
+	@property
+	def by_path(self):
+		return self._lines
+
+
 class Reader:
 	def __init__(self, artifacts, stage, page_path, take_any=False, open=open):
 		artifacts = set(artifacts)
+		if Artifact.LINES in artifacts:
+			artifacts.add(Artifact.CONTOURS)  # io.py:231-232
 		if Artifact.CONTOURS in artifacts:
 			artifacts.add(Artifact.SEGMENTATION)  # io.py:233-234
 		if stage and stage.is_dewarped and Artifact.CONTOURS in artifacts:
@@ -156,8 +209,26 @@ class Reader:
 	@property
 	def regions(self):
 		if "regions" not in self._cache:
-			self._cache["regions"] = Regions(self.path(Artifact.CONTOURS), open=self._open)
+			self._cache["regions"] = Regions(
+				self.path(Artifact.CONTOURS), lambda: self.page, self._stage, open=self._open)
 		return self._cache["regions"]
+
+	@property
+	def lines(self):
+		if "lines" not in self._cache:
+			self._cache["lines"] = Lines(
+				self.path(Artifact.LINES), self.regions, self._stage, open=self._open)
+		return self._cache["lines"]
+
+	def load_json(self, artifact):
+		with open(self.path(artifact), "r") as f:
+			return json.loads(f.read())
+
+	@property
+	def tables(self):
+		if "tables" not in self._cache:
+			self._cache["tables"] = self.load_json(Artifact.TABLES)
+		return self._cache["tables"]
 
 	@property
 	def dewarping_transform(self):
@@ -281,7 +352,7 @@ class Writer:
 
 class Output:
 	def __init__(self, *artifacts, stage=None):
-		assert all(isinstance(x, Artifact) for x in artifacts)
+		assert all(isinstance(x, (Artifact, DebuggingArtifact)) for x in artifacts)
 		self._artifacts = set(artifacts)
 		self._stage = stage
 

@@ -146,15 +146,24 @@ class Line:
 
 
 class Block:
-	"""The part of origami.core.block.Block a Line needs: its page and stage (block.py:377-402)."""
+	"""The part of origami.core.block.Block a Line needs: page, polygon and stage (block.py:377-402).
+	`page` may be a zero-argument callable: readers pass one so that listing the regions of a page
+	does not decode (and dewarp) its image."""
 
-	def __init__(self, page, stage):
+	def __init__(self, page, polygon, stage):
 		self._page = page
+		self._polygon = polygon
 		self._stage = stage
 
 	@property
 	def page(self):
+		if callable(self._page):
+			self._page = self._page()
 		return self._page
+
+	@property
+	def image_space_polygon(self):
+		return self._polygon
 
 	@property
 	def stage(self):

@@ -1,7 +1,8 @@
 """A page image and, given a dewarping grid, its dewarped form (ref: origami/core/page.py:65-117).
 
-`Page(path, grid)` remaps the full page eagerly, as the reference does (page.py:86-88) — on the GPU,
-through Dewarper (K1a + K2 fused)."""
+The reference remaps the full page as soon as a Page is opened with a grid (page.py:86-88); here that
+happens on the GPU (Dewarper: K1a + K2 fused) and on first use of `dewarped`, so that stages which only
+cut lines out of the warped page (block.py:255) do not pay for a remap they never look at."""
 
 from pathlib import Path
 
@@ -41,10 +42,8 @@ class Page:
 		self._device_page = None
 		if dewarping_transform is not None:
 			self._dewarper = Dewarper(self._warped, dewarping_transform)
-			self._dewarped = self._dewarper.dewarped
 		else:
 			self._dewarper = None
-			self._dewarped = None
 
 	@property
 	def warped(self):
@@ -52,16 +51,16 @@ class Page:
 
 	@property
 	def dewarped(self):
-		return self._dewarped
+		return self._dewarper.dewarped if self._dewarper is not None else None
 
 	def size(self, dewarped):
-		return (self._dewarped if dewarped else self._warped).size
+		return (self.dewarped if dewarped else self._warped).size
 
 	def geometry(self, dewarped):
 		return Geometry(*self.size(dewarped))
 
 	def pixels(self, dewarped):
-		return np.array(self._dewarped if dewarped else self._warped)
+		return np.array(self.dewarped if dewarped else self._warped)
 
 	@property
 	def dewarper(self):

@@ -154,3 +154,64 @@ def write_page_dir(root, name, rng, size=(2400, 3400), n_h=300, n_v=500, n_regio
 		h.save(zf, "h")
 		v.save(zf, "v")
 	return page_path
+
+
+def write_reliable_stage(page_path, rng, nodes, cell, n_lines=30, n_table_lines=4):
+	"""Adds the inputs of the line stages (OCR, line export; Stage.RELIABLE) to `<name>.out/`:
+	dewarp.zip (the given node grid), contours.3.zip, lines.3.zip, tables.json.
+	Returns {line path: (p, right, up)} in dewarped pixel coordinates."""
+	out = page_path.with_suffix(".out")
+	out.mkdir(exist_ok=True)
+	h, w = nodes.shape[:2]
+	Wd, Hd = w * cell, h * cell
+
+	data = io.BytesIO()
+	np.save(data, nodes.astype(np.float32), allow_pickle=False)
+	with zipfile.ZipFile(out / "dewarp.zip", "w", zipfile.ZIP_DEFLATED) as zf:
+		zf.writestr("data.npy", data.getvalue())
+		zf.writestr("meta.json", json.dumps(dict(version=1, cell=cell, shape=list(nodes.shape))))
+	if not (out / "segment.zip").exists():
+		with zipfile.ZipFile(out / "segment.zip", "w") as zf:
+			zf.writestr("regions.json", json.dumps(dict(name="regions", type="REGION", classes=["BACKGROUND", "TEXT", "TABULAR"])))
+
+	def geometry_of(k):
+		length = rng.uniform(0.15 * Wd, 0.8 * Wd)
+		height = rng.uniform(18, 44)
+		ang = rng.normal(0, 0.015)
+		x = rng.uniform(5, Wd - length - 5)
+		y = rng.uniform(height + 5, Hd - 5)
+		return ([x, y], [length * np.cos(ang), length * np.sin(ang)], [height * np.sin(ang), -height * np.cos(ang)])
+
+	lines = {}
+	blocks = {}
+	per_block = 5
+	for k in range(n_lines):
+		b = ("regions", "TEXT", str(k // per_block))
+		lines[b + (str(k % per_block),)] = geometry_of(k)
+		blocks[b] = None
+	# one table block whose rows are its lines; LineRewriter cuts every row at the block's column xs
+	columns = {}
+	if n_table_lines:
+		b = ("regions", "TABULAR", "7.1.1.1")
+		blocks[b] = None
+		tx, tlen = 0.1 * Wd, 0.7 * Wd
+		for k in range(n_table_lines):
+			y = (k + 1) * Hd / (n_table_lines + 2)
+			skew = rng.normal(0, 2)
+			lines[b + (str(k),)] = ([tx, y], [tlen, skew], [0.0, -rng.uniform(20, 40)])
+		columns["/".join(b)] = [tx + 0.3 * tlen, tx + 0.7 * tlen]
+
+	with zipfile.ZipFile(out / "contours.3.zip", "w", zipfile.ZIP_DEFLATED) as zf:
+		zf.writestr("meta.json", json.dumps(dict(version=2, predictions=[dict(name="regions", type="REGION")])))
+		for b in blocks:
+			ring = np.array([[1, 1], [Wd - 2, 1], [Wd - 2, Hd - 2], [1, Hd - 2], [1, 1]], dtype=np.float64)
+			zf.writestr("/".join(b) + ".wkt", to_wkt(Geom("Polygon", [ring])))
+	with zipfile.ZipFile(out / "lines.3.zip", "w", zipfile.ZIP_DEFLATED) as zf:
+		zf.writestr("meta.json", json.dumps(dict(min_confidence=0.5)))
+		for i, (path, (p, right, up)) in enumerate(lines.items()):
+			conf = 0.3 if i == 1 else 0.9  # one line below min_confidence is skipped by LineExtractor
+			zf.writestr("/".join(path) + ".json", json.dumps(dict(
+				p=p, right=right, up=up, wkt=None, confidence={"regions/TEXT": conf, "regions/BACKGROUND": 0.95},
+				tesseract_data=dict(baseline=[p, [p[0] + right[0], p[1] + right[1]]], descent=4, ascent=12, height=20))))
+	(out / "tables.json").write_text(json.dumps(dict(version=1, columns=columns, dividers={})))
+	return lines

@@ -3,6 +3,8 @@ spawned per-GPU workers) be tested on CPU."""
 
 import json
 import os
+import time
+from pathlib import Path
 
 from origami_amd.batch.core.io import Artifact, Input, Output, Stage
 from origami_amd.batch.core.processor import Processor
@@ -23,6 +25,13 @@ class FakeDewarpProcessor(Processor):
 		if page_path.stem.startswith("bad"):
 			raise RuntimeError("synthetic failure")
 		info = dict(pid=os.getpid(), rank=self._rank, device=os.environ.get("OGD_DEVICE"))
+		rendezvous = os.environ.get("FAKE_STAGE_RENDEZVOUS")  # "<dir>:<n>": hold the first page until n workers run
+		if rendezvous:
+			root, n = rendezvous.rsplit(":", 1)
+			(Path(root) / (".started.%s" % self._rank)).touch()
+			deadline = time.time() + 30
+			while len(list(Path(root).glob(".started.*"))) < int(n) and time.time() < deadline:
+				time.sleep(0.01)
 		with output.contours(copy_meta_from=warped) as zf:
 			zf.writestr("who.json", json.dumps(info))
 		with output.dewarping_transform() as f:

@@ -123,10 +123,13 @@ def test_mutexes(tmp_path):
 
 
 @pytest.mark.parametrize("lock", ["NONE", "DB"])
-def test_two_gpu_workers_share_one_queue(tmp_path, lock):
+def test_two_gpu_workers_share_one_queue(tmp_path, lock, monkeypatch):
 	"""--gpus 2: two spawned workers, bound to GPUs 0 and 1 before any HIP call, pull chunks from one
 	queue; every page is done exactly once (weak scaling, no data-path collective)."""
 	pages = make_pages(tmp_path, 9)
+	rdv = tmp_path.parent / (tmp_path.name + ".rdv")
+	rdv.mkdir()
+	monkeypatch.setenv("FAKE_STAGE_RENDEZVOUS", "%s:2" % rdv)  # no worker finishes before both have started
 	proc = FakeDewarpProcessor(options(gpus=2, devices="0,1", lock_strategy=lock))
 	assert proc.worker_devices(4) == [0, 1, 0, 1]
 	proc.traverse(tmp_path)

@@ -84,7 +84,7 @@ def test_line_mirror_matches_oracle(gpu):
 		dewarper = gdw.Dewarper(warped, gdw.Grid(nodes, s))
 		device_page = gpu.DevicePage(pixels)
 
-	block = blk.Block(FakePage, Stage.DEWARPED)
+	block = blk.Block(FakePage, None, Stage.DEWARPED)
 	geo = _lines(rng, 25, w * s, h * s)
 	lines = [blk.Line(block, v[0:2], v[2:4], v[4:6], confidence={"regions/TEXT": 0.9}) for v in geo]
 

@@ -82,3 +82,62 @@ def test_page_without_regions_is_skipped_silently(gpu, tmp_path):
 	assert res.exit_code == 0
 	out = page_path.with_suffix(".out")
 	assert not (out / "dewarp.zip").exists() and not (out / "contours.1.zip").exists()  # ref: dewarp.py:64-67
+
+
+def test_export_lines_stage_matches_oracle(gpu, tmp_path):
+	"""`export.lines` on a RELIABLE-stage page dir: every PNG equals the oracle's Line.dewarped_image
+	(ref: origami/batch/export/lines.py:51-67, batch/core/lines.py:131-149, core/block.py:223-259)."""
+	import PIL.Image
+	from oracle import block as oblock
+	from oracle import cv as ocv
+	from origami_amd.batch.export.lines import export_lines
+
+	rng = np.random.default_rng(21)
+	s, h, w = 25, 34, 26
+	size = (w * s - 20, h * s - 30)
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+	nodes = np.stack([
+		(gx - 0.5) * s + 5 * np.sin(gy / 4.0) + rng.normal(0, 0.4, size=(h, w)),
+		(gy - 0.5) * s + 5 * np.cos(gx / 5.0) + rng.normal(0, 0.4, size=(h, w))], axis=-1).astype(np.float32)
+	page_path = tmp_path / "page0001.png"
+	pixels = synth.text_page(rng, size)
+	PIL.Image.fromarray(pixels).save(page_path)
+	lines = synth.write_reliable_stage(page_path, rng, nodes, s, n_lines=30, n_table_lines=3)
+	out = page_path.with_suffix(".out")
+
+	res = CliRunner().invoke(export_lines, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	info = json.loads((out / "runtime.json").read_text())["LineExtractionProcessor"]
+	assert info["status"] == "COMPLETED", info
+
+	ogrid = odw.Grid(nodes, s)
+	tables = json.loads((out / "tables.json").read_text())["columns"]
+	with zipfile.ZipFile(out / "images.lines.dewarped.zip") as zf:
+		names = zf.namelist()
+		# 30 text lines minus the low-confidence one, 3 table rows x 3 columns
+		assert len(names) == 29 + 9
+		assert "regions/TEXT/0/1.png" not in names
+		bad = total = 0
+		for path, (p, right, up) in lines.items():
+			if path[1] == "TEXT":
+				if path == ("regions", "TEXT", "0", "1"):
+					continue
+				got = np.array(PIL.Image.open(io.BytesIO(zf.read("/".join(path) + ".png"))))
+				want = oblock.dewarped_image(pixels, ogrid, p, right, up, target_height=48)
+				assert got.shape == want.shape
+				d = np.abs(got.astype(np.int16) - want)
+				assert d.max() <= 1
+				bad += np.count_nonzero(d)
+				total += d.size
+			else:
+				block, division, _, _ = path[2].split(".")
+				xs = [None] + tables["/".join(path[:3])] + [None]
+				widths = []
+				for c in range(3):
+					name = "regions/TABULAR/%s.%s.%d.%d/0.png" % (block, division, 1 + int(path[3]), 1 + c)
+					im = PIL.Image.open(io.BytesIO(zf.read(name)))
+					assert im.size[1] == 48
+					widths.append(im.size[0])
+				full = oblock.warped_grid(ogrid, p, right, up, ysteps=48).shape[1]
+				assert abs(sum(widths) - full) <= 3 and abs(widths[1] - 0.4 * full) <= 2
+		assert bad <= 1e-3 * total
