@@ -154,6 +154,15 @@ int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, i
                        const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n,
                        int interp, uint8_t* out, const int64_t* offsets);
 
+/* ConfidenceSampler, ref: origami/batch/detect/lines.py:18-54: per line, the histogram of
+ * cv2.remap(labels, warped_grid * (sx, sy), INTER_NEAREST) — np.bincount of the remapped labels; the remapped
+ * image is never materialised.  labels: a one-channel ogd_page holding the label map; sx = w1 / w0,
+ * sy = h1 / h0 (label map size / page size, applied in float32 as scale_grid() does); rows are NOT flipped
+ * (irrelevant to a histogram); counts: [n][256] int32, overwritten. */
+int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int w, int s, float sx, float sy,
+                          const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n,
+                          int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,3 +34,16 @@ def dewarped_image(warped_pixels, grid, p0, right, up, target_height=48, interpo
 	wg = warped_grid(grid, p0, right, up, ysteps=target_height)
 	pixels = cv.remap_u8(warped_pixels, wg, interpolation)
 	return pixels[::-1, :]
+
+
+def label_evidence_counts(labels, page_shape, grid, p0, right, up, res=0.5, minlength=0):
+	"""ConfidenceSampler.__call__, batch/detect/lines.py:34-44: np.bincount of the label map remapped
+	(nearest) through the line's half-resolution lattice scaled to the label map's size.
+	page_shape: (H, W) of the warped page."""
+	wg = warped_grid(grid, p0, right, up, xres=res, yres=res)
+	h0, w0 = page_shape
+	h1, w1 = labels.shape
+	wg[:, :, 0] *= w1 / w0  # scale_grid(), lines.py:18-22 (float32 array, in place)
+	wg[:, :, 1] *= h1 / h0
+	remapped = cv.remap_u8(labels, wg, cv.INTER_NEAREST)
+	return np.bincount(remapped.flatten(), minlength=minlength)

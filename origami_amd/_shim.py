@@ -81,6 +81,9 @@ SIGNATURES = {
 	"ogd_line_images_u8": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
 		c_void_p]),
+	"ogd_line_label_counts": (c_int, [
+		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
+		c_void_p]),
 }
 
 _lib = None
@@ -268,6 +271,20 @@ class DevicePage:
 			im = out[offsets[k]:offsets[k + 1]].reshape(ys[k], xs[k], C)
 			images.append(im[:, :, 0] if self._squeeze else im)
 		return images
+
+	def line_label_counts(self, nodes, cell, lines, xsteps, ysteps, sx, sy):
+		"""This page being a label map: (n, 256) int32 histograms of the labels under each line lattice."""
+		nodes = _c(nodes, np.float32)
+		h, w = nodes.shape[:2]
+		lines = _c(lines, np.float64).reshape(-1, 6)
+		n = len(lines)
+		xs = _c(np.broadcast_to(xsteps, (n,)), np.int32)
+		ys = _c(np.broadcast_to(ysteps, (n,)), np.int32)
+		counts = np.zeros((n, 256), dtype=np.int32)
+		check(load().ogd_line_label_counts(
+			self.handle, _ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(lines), _ptr(xs), _ptr(ys),
+			n, _ptr(counts)))
+		return counts
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------

@@ -58,6 +58,30 @@ class Line:
 		return max(values) if values else 0
 
 	@property
+	def predicted_path(self):
+		if not isinstance(self._confidence, dict):
+			return None
+		items = [(k, v) for k, v in self._confidence.items() if not k.endswith("/BACKGROUND")]
+		if items:
+			return tuple(items[int(np.argmax([x[1] for x in items]))][0].split("/"))
+		return None
+
+	def predicted_path_error(self, path):
+		# block.py:91-102
+		if not isinstance(self._confidence, dict):
+			return 0
+		items = [(k, v) for k, v in self._confidence.items() if not k.endswith("/BACKGROUND")]
+		if items:
+			i = int(np.argmax([x[1] for x in items]))
+			if tuple(items[i][0].split("/")) == path:
+				return 0
+			return items[i][1] - self._confidence.get("/".join(path), 0)
+		return 0
+
+	def update_confidence(self, confidence):
+		self._confidence = confidence
+
+	@property
 	def length(self):
 		return np.linalg.norm(self._right)
 

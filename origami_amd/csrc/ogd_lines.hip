@@ -32,29 +32,62 @@ struct LineRec {        // one line, fp64, dewarped pixel coordinates
   int xsteps, ysteps;
 };
 
-template <int C, int INTERP>
-__global__ __launch_bounds__(256) void line_images_kernel(const uint8_t* __restrict__ src, int H, int W,
-                                                          ptrdiff_t ss, const float2* __restrict__ nodes,
-                                                          int h, int w, int s, double inv_s,
-                                                          const LineRec* __restrict__ lines,
-                                                          uint8_t* __restrict__ out) {
-  const LineRec L = lines[blockIdx.y];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= L.xsteps * L.ysteps) return;
-  const int r = idx / L.xsteps, j = idx - r * L.xsteps;
-  const int i = L.ysteps - 1 - r;  // pixels[::-1, :]
+// Warped-page position (x, y) of lattice sample (i, j) of a line, fp64.  ref: block.py:238-245.
+__device__ __forceinline__ double2 line_warped_xy(const LineRec& L, int i, int j, const float2* __restrict__ nodes,
+                                                  int h, int w, int s, double inv_s) {
   // np.linspace([0, 0], v, n): k * step, the last sample exactly v
   const double yx = i == L.ysteps - 1 && i > 0 ? L.ux : __dmul_rn((double)i, L.syx);
   const double yy = i == L.ysteps - 1 && i > 0 ? L.uy : __dmul_rn((double)i, L.syy);
   const double xx = j == L.xsteps - 1 && j > 0 ? L.rx : __dmul_rn((double)j, L.sxx);
   const double xy = j == L.xsteps - 1 && j > 0 ? L.ry : __dmul_rn((double)j, L.sxy);
   const double px = __dadd_rn(__dadd_rn(yx, L.p0x), xx), py = __dadd_rn(__dadd_rn(yy, L.p0y), xy);
-  const double2 wq = grid_inverse_at(nodes, h, w, s, inv_s, py, px);  // warped page (x, y)
+  return grid_inverse_at(nodes, h, w, s, inv_s, py, px);
+}
+
+template <int C, int INTERP>
+__global__ __launch_bounds__(256) void line_images_kernel(const uint8_t* __restrict__ src, int H, int W,
+                                                          ptrdiff_t ss, const float2* __restrict__ nodes,
+                                                          int h, int w, int s, double inv_s,
+                                                          const LineRec* __restrict__ lines,
+                                                          uint8_t* __restrict__ out) {
+  // a block is 4 rows x 64 columns of one line image; blocks beyond the line's own extent leave at once
+  const LineRec L = lines[blockIdx.z];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j >= L.xsteps || r >= L.ysteps) return;
+  const int idx = r * L.xsteps + j;
+  const int i = L.ysteps - 1 - r;  // pixels[::-1, :]
+  const double2 wq = line_warped_xy(L, i, j, nodes, h, w, s, inv_s);
   uint8_t o[C];
   sample_q<C, INTERP>(src, H, W, ss, quantize<INTERP>((float)wq.x), quantize<INTERP>((float)wq.y), o);
   uint8_t* d = out + L.offset + (int64_t)idx * C;
 #pragma unroll
   for (int c = 0; c < C; ++c) d[c] = o[c];
+}
+
+// Label histogram of a line's lattice: cv2.remap(labels, warped_grid * (sx, sy), INTER_NEAREST) followed by
+// np.bincount — the image itself is never written.  ref: batch/detect/lines.py:34-44 (ConfidenceSampler).
+__global__ __launch_bounds__(256) void line_label_counts_kernel(const uint8_t* __restrict__ labels, int H, int W,
+                                                                ptrdiff_t ss, const float2* __restrict__ nodes,
+                                                                int h, int w, int s, double inv_s, float sx,
+                                                                float sy, const LineRec* __restrict__ lines,
+                                                                int32_t* __restrict__ counts) {
+  __shared__ int hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const LineRec L = lines[blockIdx.z];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j < L.xsteps && i < L.ysteps) {
+    const double2 wq = line_warped_xy(L, i, j, nodes, h, w, s, inv_s);
+    // scale_grid(): float32 array times the size ratio, in float32 (lines.py:18-22)
+    const float mx = __fmul_rn((float)wq.x, sx), my = __fmul_rn((float)wq.y, sy);
+    uint8_t o[1];
+    sample_q<1, OGD_INTER_NEAREST>(labels, H, W, ss, quantize<OGD_INTER_NEAREST>(mx),
+                                   quantize<OGD_INTER_NEAREST>(my), o);
+    atomicAdd(&hist[o[0]], 1);
+  }
+  __syncthreads();
+  const int c = hist[threadIdx.x];
+  if (c) atomicAdd(&counts[(size_t)blockIdx.z * 256 + threadIdx.x], c);
 }
 
 }  // namespace ogd
@@ -120,37 +153,64 @@ int ogd_page_dewarp_u8(const ogd_page* page, const float* nodes, int h, int w, i
   return OGD_OK;
 }
 
-int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
-                       const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* out,
-                       const int64_t* offsets) {
-  OGD_REQUIRE(page != nullptr, "page is NULL");
-  OGD_REQUIRE(n >= 0, "negative line count");
-  if (n == 0) return OGD_OK;
-  OGD_REQUIRE(nodes && lines && xsteps && ysteps && out && offsets, "null pointer");
-  OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
-  OGD_REQUIRE((int64_t)h * s >= 2 && (int64_t)w * s >= 2, "dense grid must be at least 2x2");
-  OGD_REQUIRE((int64_t)h * s < INT_MAX && (int64_t)w * s < INT_MAX, "dense grid too large");
-  OGD_REQUIRE(n <= 65535, "at most 65535 lines per call (got %d)", n);
-  OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
-  OGD_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
-  const int C = page->C;
-  std::vector<LineRec> recs((size_t)n);
-  int64_t maxpix = 0;
+}  // extern "C"
+
+namespace {
+
+// Validates the line arrays and builds the device records; offsets may be NULL (no per-line output).
+int build_line_records(const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n, int C,
+                       const int64_t* offsets, std::vector<LineRec>& recs, int& max_x, int& max_y) {
+  recs.resize((size_t)n);
+  max_x = max_y = 0;
   for (int l = 0; l < n; ++l) {
     OGD_REQUIRE(xsteps[l] >= 1 && ysteps[l] >= 1, "line %d: steps must be >= 1", l);
     const int64_t pix = (int64_t)xsteps[l] * ysteps[l];
     OGD_REQUIRE(pix < INT_MAX, "line %d: image too large", l);
-    OGD_REQUIRE(offsets[l + 1] - offsets[l] == pix * C, "line %d: offsets do not match %d x %d x %d bytes", l,
-                ysteps[l], xsteps[l], C);
-    maxpix = std::max(maxpix, pix);
+    if (offsets)
+      OGD_REQUIRE(offsets[l + 1] - offsets[l] == pix * C, "line %d: offsets do not match %d x %d x %d bytes", l,
+                  ysteps[l], xsteps[l], C);
+    max_x = std::max(max_x, (int)xsteps[l]);
+    max_y = std::max(max_y, (int)ysteps[l]);
     const double* v = lines + 6 * (size_t)l;
     LineRec& r = recs[l];
     r.p0x = v[0]; r.p0y = v[1]; r.rx = v[2]; r.ry = v[3]; r.ux = v[4]; r.uy = v[5];
     const double dx = xsteps[l] > 1 ? (double)(xsteps[l] - 1) : 1.0, dy = ysteps[l] > 1 ? (double)(ysteps[l] - 1) : 1.0;
     r.sxx = r.rx / dx; r.sxy = r.ry / dx; r.syx = r.ux / dy; r.syy = r.uy / dy;
-    r.offset = offsets[l];
+    r.offset = offsets ? offsets[l] : 0;
     r.xsteps = xsteps[l]; r.ysteps = ysteps[l];
   }
+  OGD_REQUIRE((max_y + 3) / 4 <= 65535, "line image too tall (%d rows)", max_y);
+  return OGD_OK;
+}
+
+int check_line_args(const ogd_page* page, const void* nodes, int h, int w, int s, const void* lines,
+                    const void* xsteps, const void* ysteps, int n) {
+  OGD_REQUIRE(page != nullptr, "page is NULL");
+  OGD_REQUIRE(nodes && lines && xsteps && ysteps, "null pointer");
+  OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
+  OGD_REQUIRE((int64_t)h * s >= 2 && (int64_t)w * s >= 2, "dense grid must be at least 2x2");
+  OGD_REQUIRE((int64_t)h * s < INT_MAX && (int64_t)w * s < INT_MAX, "dense grid too large");
+  OGD_REQUIRE(n <= 65535, "at most 65535 lines per call (got %d)", n);
+  return OGD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
+                       const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* out,
+                       const int64_t* offsets) {
+  OGD_REQUIRE(n >= 0, "negative line count");
+  if (n == 0) return OGD_OK;
+  OGD_TRY(check_line_args(page, nodes, h, w, s, lines, xsteps, ysteps, n));
+  OGD_REQUIRE(out && offsets, "null pointer");
+  OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
+  OGD_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+  const int C = page->C;
+  std::vector<LineRec> recs;
+  int max_x = 0, max_y = 0;
+  OGD_TRY(build_line_records(lines, xsteps, ysteps, n, C, offsets, recs, max_x, max_y));
   OGD_TRY(ensure_device());
   const size_t nb = (size_t)h * w * 2 * sizeof(float), ob = (size_t)offsets[n];
   DevBuf dn, dl, dout;
@@ -159,7 +219,7 @@ int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, i
   OGD_TRY(dout.alloc(ob));
   OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
   OGD_HIP(hipMemcpy(dl.p, recs.data(), recs.size() * sizeof(LineRec), hipMemcpyHostToDevice));
-  const dim3 grid((unsigned)((maxpix + 255) / 256), (unsigned)n), block(256);
+  const dim3 grid((unsigned)((max_x + 63) / 64), (unsigned)((max_y + 3) / 4), (unsigned)n), block(256);
   const float2* dnodes = dn.as<float2>();
   const double inv_s = 1.0 / (double)s;
 #define OGD_LINES(CC, II)                                                                                  \
@@ -173,6 +233,35 @@ int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, i
 #undef OGD_LINES
   OGD_TRY(check_launch("line_images_kernel"));
   OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int w, int s, float sx, float sy,
+                          const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n,
+                          int32_t* counts) {
+  OGD_REQUIRE(n >= 0, "negative line count");
+  if (n == 0) return OGD_OK;
+  OGD_TRY(check_line_args(labels, nodes, h, w, s, lines, xsteps, ysteps, n));
+  OGD_REQUIRE(counts != nullptr, "null pointer");
+  OGD_REQUIRE(labels->C == 1, "label map must have one channel (has %d)", labels->C);
+  std::vector<LineRec> recs;
+  int max_x = 0, max_y = 0;
+  OGD_TRY(build_line_records(lines, xsteps, ysteps, n, 1, nullptr, recs, max_x, max_y));
+  OGD_TRY(ensure_device());
+  const size_t nb = (size_t)h * w * 2 * sizeof(float), cb = (size_t)n * 256 * sizeof(int32_t);
+  DevBuf dn, dl, dc;
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(dl.alloc(recs.size() * sizeof(LineRec)));
+  OGD_TRY(dc.alloc(cb));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(dl.p, recs.data(), recs.size() * sizeof(LineRec), hipMemcpyHostToDevice));
+  OGD_HIP(hipMemsetAsync(dc.p, 0, cb, nullptr));
+  const dim3 grid((unsigned)((max_x + 63) / 64), (unsigned)((max_y + 3) / 4), (unsigned)n), block(256);
+  hipLaunchKernelGGL(line_label_counts_kernel, grid, block, 0, nullptr, labels->d, labels->H, labels->W,
+                     labels->stride, dn.as<float2>(), h, w, s, 1.0 / (double)s, sx, sy, dl.as<LineRec>(),
+                     dc.as<int32_t>());
+  OGD_TRY(check_launch("line_label_counts_kernel"));
+  OGD_HIP(hipMemcpy(counts, dc.p, cb, hipMemcpyDeviceToHost));
   return OGD_OK;
 }
 

@@ -87,6 +87,8 @@ __device__ __forceinline__ double2 grid_inverse_at(NodePtr nodes, int h, int w, 
   const double ty = y - (double)iy, tx = x - (double)ix;
   const Tap ax0 = tap_x(ix, inv_s, w), ax1 = tap_x(ix + 1, inv_s, w);
   const Tap ay0 = tap_y(iy, inv_s, h), ay1 = tap_y(iy + 1, inv_s, h);
+  // (sharing the node loads when the four pixels lie in one node cell was measured: a 64-px wavefront always
+  // straddles a 25-px cell border, both branches run, nothing gained)
   const float2 v00 = dense_at(nodes, w, ax0, ay0), v01 = dense_at(nodes, w, ax1, ay0);
   const float2 v10 = dense_at(nodes, w, ax0, ay1), v11 = dense_at(nodes, w, ax1, ay1);
   const double w00 = __dmul_rn(1.0 - ty, 1.0 - tx), w01 = __dmul_rn(1.0 - ty, tx);

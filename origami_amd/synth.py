@@ -132,7 +132,8 @@ def write_page_dir(root, name, rng, size=(2400, 3400), n_h=300, n_v=500, n_regio
 			data = io.BytesIO()
 			im.save(data, format="PNG")
 			zf.writestr("%s.png" % pname, data.getvalue())
-			zf.writestr("%s.json" % pname, json.dumps(dict(name=pname, type=ptype, classes=classes)))
+			zf.writestr("%s.json" % pname, json.dumps(dict(
+				name=pname, type=ptype, classes=dict((c, i) for i, c in enumerate(classes)))))
 
 	scale = W / label_size[0]
 	with zipfile.ZipFile(out / "contours.0.zip", "w", zipfile.ZIP_DEFLATED) as zf:
@@ -172,7 +173,8 @@ def write_reliable_stage(page_path, rng, nodes, cell, n_lines=30, n_table_lines=
 		zf.writestr("meta.json", json.dumps(dict(version=1, cell=cell, shape=list(nodes.shape))))
 	if not (out / "segment.zip").exists():
 		with zipfile.ZipFile(out / "segment.zip", "w") as zf:
-			zf.writestr("regions.json", json.dumps(dict(name="regions", type="REGION", classes=["BACKGROUND", "TEXT", "TABULAR"])))
+			zf.writestr("regions.json", json.dumps(dict(
+				name="regions", type="REGION", classes=dict(BACKGROUND=0, TEXT=1, TABULAR=2))))
 
 	def geometry_of(k):
 		length = rng.uniform(0.15 * Wd, 0.8 * Wd)

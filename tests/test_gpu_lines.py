@@ -141,3 +141,67 @@ def test_line_images_reject_bad_arguments(gpu):
 			dp.line_images(nodes, 8, np.zeros((1, 6)), [0], [48])
 	with pytest.raises(ValueError, match="closed"):
 		dp.line_images(nodes, 8, np.zeros((1, 6)), [4], [4])
+
+
+def test_line_label_counts_match_oracle(gpu):
+	"""ConfidenceSampler (ref: batch/detect/lines.py:25-54): histogram of the nearest-remapped label map
+	under each line's half-resolution lattice.  Bar: label work is bit-exact except where the float32 cast
+	of the fp64 inverse map flips a round-to-nearest tie: <= 0.1 % of samples may land in another bin."""
+	from origami_amd import block as blk
+	from origami_amd import dewarp as gdw
+	from origami_amd.batch.detect.lines import ConfidenceSampler
+	from origami_amd.segment import Prediction, Segmentation
+	from origami_amd.batch.core.io import PredictorType
+	import enum
+	import PIL.Image
+
+	rng = np.random.default_rng(9)
+	h, w, s = 30, 22, 25
+	nodes = _nodes(rng, h, w, s)
+	ogrid = odw.Grid(nodes, s)
+	W, H = w * s - 30, h * s - 40
+	pixels = synth.text_page(rng, (W, H))
+	labels = synth.label_map(rng, (W // 3, H // 3 + 7), n_classes=4, blocks=9)
+	assert labels.shape == (H // 3 + 7, W // 3) and labels.dtype == np.uint8
+	geo = _lines(rng, 30, w * s, h * s)
+
+	# C ABI level, explicit steps
+	xsteps = rng.integers(2, 200, size=len(geo)).astype(np.int32)
+	ysteps = rng.integers(2, 30, size=len(geo)).astype(np.int32)
+	sx, sy = np.float32(labels.shape[1] / W), np.float32(labels.shape[0] / H)
+	with gpu.DevicePage(labels) as dl:
+		got = dl.line_label_counts(nodes, s, geo, xsteps, ysteps, sx, sy)
+	assert got.shape == (len(geo), 256) and got.dtype == np.int32
+	moved = total = 0
+	for k, v in enumerate(geo):
+		wg = oblock.warped_grid(ogrid, v[0:2], v[2:4], v[4:6], xsteps=int(xsteps[k]), ysteps=int(ysteps[k]))
+		wg[:, :, 0] *= labels.shape[1] / W
+		wg[:, :, 1] *= labels.shape[0] / H
+		want = np.bincount(ocv.remap_u8(labels, wg, ocv.INTER_NEAREST).flatten(), minlength=256)
+		assert got[k].sum() == want.sum() == int(xsteps[k]) * int(ysteps[k])
+		moved += np.abs(got[k] - want).sum() // 2
+		total += want.sum()
+	assert moved <= 1e-3 * total, (moved, total)
+
+	# the reference's interface
+	class FakePage:
+		warped = PIL.Image.fromarray(pixels)
+		dewarper = gdw.Dewarper(warped, gdw.Grid(nodes, s))
+
+	classes = enum.Enum("RegionLabel", dict(BACKGROUND=0, TEXT=1, TABULAR=2, ILLUSTRATION=3))
+	seg = Segmentation([Prediction(PredictorType.REGION, "regions", labels, classes)])
+	block = blk.Block(FakePage, None, Stage.AGGREGATE)
+	lines = [blk.Line(block, v[0:2], v[2:4], v[4:6]) for v in geo]
+	sampler = ConfidenceSampler({("regions", "TEXT", "0"): block}, seg)
+	evidence = sampler.sample_many([(("regions", "TEXT", "0"), ln) for ln in lines])
+	for ev, v in zip(evidence, geo):
+		want = oblock.label_evidence_counts(labels, (H, W), ogrid, v[0:2], v[2:4], v[4:6], minlength=4)
+		assert sorted(ev) == ["regions/BACKGROUND", "regions/ILLUSTRATION", "regions/TABULAR", "regions/TEXT"]
+		for c in classes:
+			assert ev["regions/%s" % c.name] == pytest.approx(want[c.value] / want.sum(), abs=2e-3)
+		assert sum(ev.values()) == pytest.approx(1.0)
+	one = sampler(("regions", "TEXT", "0"), lines[4])
+	assert one == evidence[4]
+	lines[4].update_confidence(one)
+	assert lines[4].confidence == max(v for k, v in one.items() if not k.endswith("/BACKGROUND"))
+	sampler.close()
