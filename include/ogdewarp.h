@@ -32,7 +32,8 @@ typedef enum ogd_status {
   OGD_ERR_INVALID = -1,  /* bad argument (shape, null pointer, unsupported channel count ...) */
   OGD_ERR_HIP = -2,      /* a HIP runtime call failed; ogd_last_error() has hipGetErrorString */
   OGD_ERR_NOMEM = -3,    /* host or device allocation failed */
-  OGD_ERR_NODEVICE = -4  /* no gfx950 device visible */
+  OGD_ERR_NODEVICE = -4, /* no gfx950 device visible */
+  OGD_ERR_UNSUPPORTED = -5 /* input outside the domain of a fast set-up path; take the general one */
 } ogd_status;
 
 #define OGD_INTER_NEAREST 0 /* cv2.INTER_NEAREST */
@@ -162,6 +163,19 @@ int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, i
 int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int w, int s, float sx, float sy,
                           const double* lines, const int32_t* xsteps, const int32_t* ysteps, int n,
                           int32_t* counts);
+
+/* ---- Transformer set-up without Qhull --------------------------------------------
+ * ref: origami/core/dewarp.py:143-161 (LinearNDInterpolator over the h x w node positions),
+ * origami/core/lingrid.py:208-221, 286-290 (scipy.spatial.ConvexHull + Delaunay of the same points).
+ * Host code, no device work: the Delaunay triangulation of a warped lattice from its known topology
+ * (quads split, hull pockets ear-clipped, Lawson flips with exact predicates) instead of a general hull code.
+ * pts: [h*w][2] float64 row-major lattice positions.  simplices: [cap][3] vertex indices (cap >= 2*h*w is
+ * always enough); hull: [2*(h+w)] strict convex hull vertices, counter-clockwise like ConvexHull.vertices;
+ * transform: NULL or [cap][3][2] in the layout of scipy.spatial.Delaunay.transform.
+ * Returns OGD_ERR_UNSUPPORTED for a folded / degenerate lattice or coordinates outside the exact domain
+ * (|x| < 2^20, multiples of 2^-40 — any float32 grid): the caller then runs Qhull as before. */
+int ogd_lattice_delaunay(const double* pts, int h, int w, int32_t* simplices, int64_t cap,
+                         int64_t* n_simplices, int32_t* hull, int* n_hull, double* transform);
 
 #ifdef __cplusplus
 }

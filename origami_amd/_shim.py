@@ -81,6 +81,8 @@ SIGNATURES = {
 	"ogd_line_images_u8": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
 		c_void_p]),
+	"ogd_lattice_delaunay": (c_int, [
+		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
 	"ogd_line_label_counts": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
 		c_void_p]),
@@ -285,6 +287,28 @@ class DevicePage:
 			self.handle, _ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(lines), _ptr(xs), _ptr(ys),
 			n, _ptr(counts)))
 		return counts
+
+
+# ---- N3: lattice Delaunay (host) --------------------------------------------------------------------
+
+ERR_UNSUPPORTED = -5
+
+
+def lattice_delaunay(points_hw2):
+	"""(h, w, 2) lattice positions -> (simplices (nt, 3) int32, hull vertex indices, transform (nt, 3, 2)),
+	as scipy.spatial.Delaunay / ConvexHull give them; raises OgdError(ERR_UNSUPPORTED) outside its domain."""
+	pts = _c(points_hw2, np.float64)
+	if pts.ndim != 3 or pts.shape[2] != 2:
+		raise ValueError("lattice must have shape (h, w, 2)")
+	h, w = pts.shape[:2]
+	cap = 2 * h * w
+	simplices = np.empty((cap, 3), dtype=np.int32)
+	transform = np.empty((cap, 3, 2), dtype=np.float64)
+	hull = np.empty(2 * (h + w), dtype=np.int32)
+	nt, nh = c_int64(0), c_int(0)
+	check(load().ogd_lattice_delaunay(
+		_ptr(pts), h, w, _ptr(simplices), cap, ctypes.byref(nt), _ptr(hull), ctypes.byref(nh), _ptr(transform)))
+	return simplices[:nt.value], hull[:nh.value], transform[:nt.value]
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------

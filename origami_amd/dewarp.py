@@ -154,7 +154,8 @@ class Transformer:
 		bounds = (
 			np.min(source[:, 0]), np.min(source[:, 1]),
 			np.max(source[:, 0]), np.max(source[:, 1]))
-		self._interp = lininterp(source, target, bounds)
+		# the nodes are a warped lattice: triangulated from that topology, not by Qhull
+		self._interp = lininterp(source, target, bounds, lattice_shape=(h, w))
 
 	def __call__(self, x, y):
 		pts = self._interp(np.squeeze(np.dstack([x, y]), axis=0))

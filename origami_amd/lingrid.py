@@ -180,7 +180,11 @@ class Interpolator:
 class InterpolatorFactory:
 	"""ref: lingrid.py:192-293."""
 
-	def __init__(self, points, values, bounds):
+	def __init__(self, points, values, bounds, lattice_shape=None):
+		"""lattice_shape=(h, w): `points` are the row-major nodes of a warped lattice (the Transformer's
+		input).  Hull and Delaunay triangulation then come from ogd_lattice_delaunay (known topology,
+		exact Lawson flips, identical to Qhull's result wherever that is unique) instead of two Qhull
+		runs; inputs outside its domain fall back to Qhull."""
 		if len(values) < 2:
 			raise ValueError("not enough values given.")
 
@@ -194,8 +198,19 @@ class InterpolatorFactory:
 		box = Box(*bounds)
 		pts, vals = self._points, self._values
 
+		self._lattice = None
+		if lattice_shape is not None and tuple(lattice_shape) >= (2, 2):
+			h, w = lattice_shape
+			try:
+				self._lattice = _shim.lattice_delaunay(pts.reshape(h, w, 2))
+			except _shim.OgdError as e:
+				if e.status != _shim.ERR_UNSUPPORTED:
+					raise
 		try:
-			hull = scipy.spatial.ConvexHull(pts)  # vertices counter-clockwise in 2-D
+			if self._lattice is not None:
+				hull_vertices = self._lattice[1]
+			else:
+				hull_vertices = scipy.spatial.ConvexHull(pts).vertices  # counter-clockwise in 2-D
 			self._is_collinear = False
 		except QhullError:
 			self._is_collinear = True  # most probably points are collinear
@@ -203,9 +218,12 @@ class InterpolatorFactory:
 		head_pts, head_val = [], []
 		if not self._is_collinear:
 			# of coincident input points the reference keeps the value of the last one (dict build)
-			last = dict(zip(map(tuple, pts.tolist()), range(len(pts))))
-			idx = [last[tuple(pts[i].tolist())] for i in hull.vertices]
-			ring = np.hstack([pts[hull.vertices], vals[idx].reshape(len(idx), -1)])
+			if self._lattice is not None:
+				idx = list(hull_vertices)  # a lattice that passed ogd_lattice_delaunay has no coincident nodes
+			else:
+				last = dict(zip(map(tuple, pts.tolist()), range(len(pts))))
+				idx = [last[tuple(pts[i].tolist())] for i in hull_vertices]
+			ring = np.hstack([pts[hull_vertices], vals[idx].reshape(len(idx), -1)])
 			for a, b in zip(ring, np.roll(ring, -1, axis=0)):
 				box.add_projection(a, b)
 			head_pts = list(ring[:, :2])
@@ -251,7 +269,11 @@ class InterpolatorFactory:
 		if self._interpolator is None:
 			extra = self._triangulate(self._extra_pts, self._extra_val)
 			inter = None
-			if not self._is_collinear:
+			if self._lattice is not None:
+				simplices, _, transform = self._lattice
+				inter = _shim.Triangulation(self._points, simplices, self._values, transform)
+				self._lattice = None
+			elif not self._is_collinear:
 				inter = self._triangulate(self._points, self._values)
 			self._interpolator = Interpolator(inter, extra, self._bounds, self._squeeze)
 		return self._interpolator
@@ -272,5 +294,5 @@ def lingrid(points, values, width, height):
 	return InterpolatorFactory(points, values, (0, 0, width - 1, height - 1)).grid
 
 
-def lininterp(points, values, bounds):
-	return InterpolatorFactory(points, values, bounds).interpolator
+def lininterp(points, values, bounds, lattice_shape=None):
+	return InterpolatorFactory(points, values, bounds, lattice_shape=lattice_shape).interpolator

@@ -187,3 +187,92 @@ def test_line_position_with_column():
 	p0, right, up, xres = ln._position(1, (-50.0, 400.0))
 	np.testing.assert_allclose(p0, [10.0, 100.0])
 	np.testing.assert_allclose(right, [200.0, 4.0])
+
+
+# ---- N3: lattice Delaunay (host code of the library, no device) ---------------------------------------
+
+def _warped_lattice(rng, h, w, s=25, amp=6.0):
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+	x = (gx - 1) * s + amp * np.sin(gy / 3.0) + rng.normal(0, 0.5, size=(h, w))
+	y = (gy - 1) * s + amp * np.cos(gx / 4.0) + rng.normal(0, 0.5, size=(h, w))
+	return np.stack([x, y], axis=-1).astype(np.float32)
+
+
+def _tri_set(simplices):
+	return set(map(tuple, np.sort(simplices, axis=1).tolist()))
+
+
+@pytest.mark.parametrize("shape,mirror", [((12, 9), False), ((2, 2), False), ((2, 40), False), ((60, 45), False), ((20, 15), True)])
+def test_lattice_delaunay_equals_qhull(shape, mirror):
+	"""ogd_lattice_delaunay (known topology + exact Lawson flips) gives Qhull's triangulation, hull and
+	barycentric transforms on warped lattices (ref: dewarp.py:143-161 via lingrid.py:208-221, 286-290)."""
+	import scipy.spatial
+	from origami_amd import _shim
+	rng = np.random.default_rng(shape[0] * 100 + shape[1])
+	nodes = _warped_lattice(rng, *shape)
+	if mirror:
+		nodes = np.ascontiguousarray(nodes[:, ::-1])
+	pts = nodes.reshape(-1, 2).astype(np.float64)
+	simplices, hull, transform = _shim.lattice_delaunay(nodes)
+	ref = scipy.spatial.Delaunay(pts)
+	assert _tri_set(simplices) == _tri_set(ref.simplices)
+	hv = list(scipy.spatial.ConvexHull(pts).vertices)
+	k = hv.index(hull[0])
+	assert hv[k:] + hv[:k] == list(hull)  # same vertices, same (counter-clockwise) cyclic order
+	# transforms: same barycentric coordinates per vertex for points around each triangle
+	lut = {tuple(sorted(s)): i for i, s in enumerate(ref.simplices.tolist())}
+	for i, s in enumerate(simplices.tolist()):
+		j = lut[tuple(sorted(s))]
+		x = pts[s].mean(axis=0) + rng.normal(0, 3, 2)
+
+		def bary(T, verts):
+			c = T[:2] @ (x - T[2])
+			return dict(zip(verts, [c[0], c[1], 1 - c[0] - c[1]]))
+		a, b = bary(transform[i], s), bary(ref.transform[j], ref.simplices[j].tolist())
+		assert max(abs(a[v] - b[v]) for v in s) < 1e-9  # slivers in hull pockets are ill-conditioned
+
+
+def test_lattice_delaunay_concave_outline_and_collinear_edges():
+	"""Pockets between a bowed outline and its hull are filled; outline nodes exactly on a hull edge split them."""
+	import scipy.spatial
+	from origami_amd import _shim
+	h, w = 9, 11
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+	x = gx * 16 + 3 * np.sin(np.pi * gy / (h - 1))  # left side bows inwards, right side outwards
+	y = gy * 16 - 5 * np.sin(np.pi * gx / (w - 1)) * (gy == 0) + 4 * np.sin(np.pi * gx / (w - 1)) * (gy == h - 1)
+	nodes = (np.round(np.stack([x, y], axis=-1) * 64) / 64).astype(np.float32)  # sin(pi) leaves 1e-16 otherwise
+	nodes[h - 1, :, 1] = nodes[h - 1, 0, 1]  # bottom row exactly straight: its nodes lie ON the hull edge
+	pts = nodes.reshape(-1, 2).astype(np.float64)
+	simplices, hull, _ = _shim.lattice_delaunay(nodes)
+	ref = scipy.spatial.Delaunay(pts)
+	def area(s):
+		u, v = pts[s[:, 1]] - pts[s[:, 0]], pts[s[:, 2]] - pts[s[:, 0]]
+		return 0.5 * np.abs(u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]).sum()
+	assert area(simplices) == pytest.approx(scipy.spatial.ConvexHull(pts).volume, rel=1e-12)
+	assert len(simplices) > 2 * (h - 1) * (w - 1)  # pockets were added
+	ours, theirs = _tri_set(simplices), _tri_set(ref.simplices)
+	# the regular interior is all cocircular quads (either diagonal is Delaunay): compare where unique
+	cocircular_ok = all(len(set(t)) == 3 for t in ours ^ theirs)
+	assert cocircular_ok and len(ours) == len(theirs)
+	assert set(hull) == set(scipy.spatial.ConvexHull(pts).vertices)
+
+
+def test_lattice_delaunay_rejects_what_it_cannot_do():
+	from origami_amd import _shim
+	rng = np.random.default_rng(3)
+	nodes = _warped_lattice(rng, 8, 8)
+	folded = nodes.copy()
+	folded[3, 3] = folded[5, 5]  # coincident / folded cell
+	with pytest.raises(_shim.OgdError) as e:
+		_shim.lattice_delaunay(folded)
+	assert e.value.status == _shim.ERR_UNSUPPORTED
+	inexact = nodes.astype(np.float64)
+	inexact[2, 2, 0] += 2.0 ** -45  # not a multiple of 2^-40
+	with pytest.raises(_shim.OgdError) as e:
+		_shim.lattice_delaunay(inexact)
+	assert e.value.status == _shim.ERR_UNSUPPORTED
+	huge = nodes.astype(np.float64)
+	huge[0, 0, 0] = -3e6
+	with pytest.raises(_shim.OgdError) as e:
+		_shim.lattice_delaunay(huge)
+	assert e.value.status == _shim.ERR_UNSUPPORTED
