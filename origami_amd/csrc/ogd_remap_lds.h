@@ -42,23 +42,34 @@ typedef const float2 RL_GLOBAL* rl_gf2;
 __device__ __forceinline__ rl_s2 rl_as_s2(int v) { return __builtin_bit_cast(rl_s2, v); }
 __device__ __forceinline__ int rl_as_int(rl_s2 v) { return __builtin_bit_cast(int, v); }
 
-// Packed (int16 x 2) min / max over the wavefront; the result is valid in lane 63.
-template <bool IS_MIN>
-__device__ __forceinline__ int rl_wave_reduce_pk(int v) {
-#define RL_STEP(ctrl)                                                                    \
-  {                                                                                      \
-    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);              \
-    v = rl_as_int(IS_MIN ? __builtin_elementwise_min(rl_as_s2(v), rl_as_s2(o))           \
-                         : __builtin_elementwise_max(rl_as_s2(v), rl_as_s2(o)));         \
+// Packed (int16 x 2) min of `mn` and max of `mx` over the wavefront (results broadcast through lane 63).
+// The two chains are interleaved so that each fills the other's DPP wait states; the first four steps
+// move with an undefined `old` (every lane has a source lane), which spares the copy of the tied operand.
+__device__ __forceinline__ void rl_wave_reduce_minmax(int& mn, int& mx) {
+#define RL_STEP(ctrl)                                                                     \
+  {                                                                                       \
+    const int a = __builtin_amdgcn_mov_dpp(mn, ctrl, 0xF, 0xF, true);                     \
+    const int b = __builtin_amdgcn_mov_dpp(mx, ctrl, 0xF, 0xF, true);                     \
+    mn = rl_as_int(__builtin_elementwise_min(rl_as_s2(mn), rl_as_s2(a)));                 \
+    mx = rl_as_int(__builtin_elementwise_max(rl_as_s2(mx), rl_as_s2(b)));                 \
   }
-  RL_STEP(0xB1)   // quad_perm [1,0,3,2]
-  RL_STEP(0x4E)   // quad_perm [2,3,0,1]
-  RL_STEP(0x141)  // row_half_mirror
-  RL_STEP(0x140)  // row_mirror
-  RL_STEP(0x142)  // row_bcast15
-  RL_STEP(0x143)  // row_bcast31
+#define RL_STEP_B(ctrl)                                                                   \
+  {                                                                                       \
+    const int a = __builtin_amdgcn_update_dpp(mn, mn, ctrl, 0xF, 0xF, false);             \
+    const int b = __builtin_amdgcn_update_dpp(mx, mx, ctrl, 0xF, 0xF, false);             \
+    mn = rl_as_int(__builtin_elementwise_min(rl_as_s2(mn), rl_as_s2(a)));                 \
+    mx = rl_as_int(__builtin_elementwise_max(rl_as_s2(mx), rl_as_s2(b)));                 \
+  }
+  RL_STEP(0xB1)     // quad_perm [1,0,3,2]
+  RL_STEP(0x4E)     // quad_perm [2,3,0,1]
+  RL_STEP(0x141)    // row_half_mirror
+  RL_STEP(0x140)    // row_mirror
+  RL_STEP_B(0x142)  // row_bcast15
+  RL_STEP_B(0x143)  // row_bcast31
 #undef RL_STEP
-  return __builtin_amdgcn_readlane(v, 63);
+#undef RL_STEP_B
+  mn = __builtin_amdgcn_readlane(mn, 63);
+  mx = __builtin_amdgcn_readlane(mx, 63);
 }
 
 // ---- where the map comes from ------------------------------------------------------------------------
@@ -220,8 +231,13 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH);
 
   // 1. + 2. (see the file comment for the clamp)
-  const float xlo = LIN ? -64.f : -1.f, xhi = LIN ? (float)(W * 32) : (float)W;
-  const float ylo = xlo, yhi = LIN ? (float)(H * 32) : (float)H;
+  // Quantisation without a float->int conversion: for |v| < 2^22, v + 1.5 * 2^23 rounds v to the nearest
+  // integer, ties to even, in the adder (that is cvRound), and leaves it in the low mantissa bits.  The
+  // product m * 32 is exact, so one fma gives cvRound(m * 32); the clamp (applied to m: the bounds are
+  // multiples of 32) keeps the sum inside [2^23, 2^24) and sends NaN / huge values to the border.
+  const float xlo = LIN ? -2.f : -1.f, xhi = (float)W;
+  const float ylo = xlo, yhi = (float)H;
+  constexpr float MAGIC = 12582912.f;  // 1.5 * 2^23; bit pattern 0x4B400000, a multiple of 32
   int lp[RPT][4];
   uint32_t wa[RPT][4], wb[RPT][4];
   int mn = 0x7fff7fff, mx = (int)0x80008000;
@@ -229,15 +245,15 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   for (int r = 0; r < RPT; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float ax = LIN ? __fmul_rn(mv[r][2 * k], 32.f) : mv[r][2 * k];
-      const float ay = LIN ? __fmul_rn(mv[r][2 * k + 1], 32.f) : mv[r][2 * k + 1];
-      const int qx = (int)rintf(__builtin_amdgcn_fmed3f(ax, xlo, xhi));
-      const int qy = (int)rintf(__builtin_amdgcn_fmed3f(ay, ylo, yhi));
-      const int cx = qx >> SHIFT, cy = qy >> SHIFT;
+      const float cxf = __builtin_amdgcn_fmed3f(mv[r][2 * k], xlo, xhi);
+      const float cyf = __builtin_amdgcn_fmed3f(mv[r][2 * k + 1], ylo, yhi);
+      const uint32_t qbx = __float_as_uint(LIN ? __builtin_fmaf(cxf, 32.f, MAGIC) : __fadd_rn(cxf, MAGIC));
+      const uint32_t qby = __float_as_uint(LIN ? __builtin_fmaf(cyf, 32.f, MAGIC) : __fadd_rn(cyf, MAGIC));
+      const int cx = __builtin_amdgcn_sbfe((int)qbx, SHIFT, 16), cy = __builtin_amdgcn_sbfe((int)qby, SHIFT, 16);
       lp[r][k] = __mul24(cy, PF) + (C == 1 ? cx : __mul24(cx, C));
       if (LIN) {
-        wa[r][k] = __umul24(qx & 31, 255) + 32;              // (32 - fx) | fx << 8
-        wb[r][k] = __umul24(qy & 31, 64 * 65535) + 64 * 32;  // 64 * ((32 - fy) | fy << 16)
+        wa[r][k] = __umul24(qbx & 31, 255) + 32;              // (32 - fx) | fx << 8
+        wb[r][k] = __umul24(qby & 31, 64 * 65535) + 64 * 32;  // 64 * ((32 - fy) | fy << 16)
       }
       asm volatile("" : "+v"(lp[r][k]));
       if (LIN) asm volatile("" : "+v"(wa[r][k]), "+v"(wb[r][k]));
@@ -245,8 +261,7 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
       mn = rl_as_int(__builtin_elementwise_min(rl_as_s2(mn), rl_as_s2(pc)));
       mx = rl_as_int(__builtin_elementwise_max(rl_as_s2(mx), rl_as_s2(pc)));
     }
-  mn = rl_wave_reduce_pk<true>(mn);
-  mx = rl_wave_reduce_pk<false>(mx);
+  rl_wave_reduce_minmax(mn, mx);
   const int mnx = (short)(mn & 0xffff), mny = mn >> 16, mxx = (short)(mx & 0xffff), mxy = mx >> 16;
   const int x0b = (mnx * C) & ~3;
   const int wbytes = (mxx + TAPS) * C - x0b;
@@ -257,8 +272,33 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   }
 
   // 3. stage: lanes cover (row, dword) pairs, 32 or 64 dwords per window row
-  {
-    const int P4 = (wbytes + 3) >> 2, WB = W * C;
+  const int P4 = (wbytes + 3) >> 2, WB = W * C;
+  if (x0b >= 0 && x0b + 4 * P4 <= WB && mny >= 0 && mny + nrows <= H) {  // wave-uniform
+    // window inside the image (all but the tiles on the page border): no per-dword tests, and the
+    // loads of up to 8 window rows per lane are all in flight before the first one is written to LDS
+    // (one memory round trip per tile instead of one per row pair)
+    constexpr int U = 8;
+    const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
+    const int r0 = lane >> sh;
+    const uint8_t* pw = src + ((ptrdiff_t)mny * ss + x0b);  // wave-uniform base + 32-bit lane offsets
+    const uint32_t ss32 = (uint32_t)ss;                      // the window lies inside the image: ss > 0
+    for (int c = lane & (cw - 1); c < P4; c += cw) {
+      for (int rb = 0; rb < nrows; rb += U * rp) {  // wave-uniform trip count
+        // rows past the window re-read and re-write its last row (same bytes): no predication
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t row = (uint32_t)min(rb + r0 + u * rp, nrows - 1);
+          v[u] = *reinterpret_cast<const rl_u32u*>(pw + (row * ss32 + 4u * (uint32_t)c));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int row = min(rb + r0 + u * rp, nrows - 1);
+          win[row * (PF / 4) + c] = v[u];
+        }
+      }
+    }
+  } else {
     const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
     for (int c = lane & (cw - 1); c < P4; c += cw) {
       const int xb = x0b + 4 * c;
