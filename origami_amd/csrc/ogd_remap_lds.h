@@ -88,7 +88,7 @@ struct MapGlobal {
   }
 
   template <int LX, int RPT>
-  __device__ __forceinline__ void load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int) const {
+  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int) const {
     constexpr int RW = 64 / LX;
     if (X + 4 <= Wd) {
 #pragma unroll
@@ -108,6 +108,7 @@ struct MapGlobal {
           mv[r][2 * k + 1] = v.y;
         }
     }
+    return true;
   }
 };
 
@@ -125,61 +126,69 @@ struct MapNodes {
     return make_float2(__fmul_rn(v.x, scx), __fmul_rn(v.y, scy));
   }
 
-  // `lds` is the wavefront's window slice (free until the window is staged): the node sub-grid the
-  // tile touches is staged there first, so every pixel reads its four nodes from LDS instead of
-  // issuing four global loads.  (X0, Y0) is the tile origin.
+  // `lds` is the wavefront's window slice (free until the window is staged).  The map of the tile is built
+  // in it the way cv2.resize builds it, separably: (0) the node sub-grid the tile touches, (1) one
+  // horizontally lerped row per touched node row (lane = tile column: the x tap, with its fp64
+  // arithmetic, is computed once per column and wavefront, not once per pixel), (2) per pixel only the
+  // vertical lerp of two such rows.  Same operations in the same order as dense_at, hence the same bits.
+  // (X0, Y0) is the tile origin.
+  // Returns false (wave-uniform) when the sub-grid does not fit the slice (cells of a pixel or two): the
+  // caller then takes the per-pixel path for the tile.
   template <int LX, int RPT>
-  __device__ __forceinline__ void load(int X, int Yb, float (&mv)[RPT][8], uint32_t* lds, int lds_dwords,
+  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t* lds, int lds_dwords,
                                        int lane, int X0, int Y0) const {
     constexpr int RW = 64 / LX, TW = 4 * LX, TH = RW * RPT;
-    const int jlo = tap_x(X0, inv_s, w).i0, jhi = tap_x(min(X0 + TW - 1, Wd - 1), inv_s, w).i1;
-    const int ilo = tap_y(Y0, inv_s, h).i0, ihi = tap_y(min(Y0 + TH - 1, Hd - 1), inv_s, h).i1;
-    const int nc = jhi - jlo + 1, nn = nc * (ihi - ilo + 1);
-    const bool in_lds = 2 * nn <= lds_dwords;  // wave-uniform
-    float2* ln = reinterpret_cast<float2*>(lds);
-    if (in_lds) {
+    static_assert(TW <= 64 && TH <= 64, "one tile column / row per lane");
+    // lane l: x tap of tile column l, y tap of tile row l (clamped to the tile; the taps are monotone)
+    const Tap txl = tap_x(min(X0 + min(lane, TW - 1), Wd - 1), inv_s, w);
+    const Tap tyl = tap_y(min(Y0 + min(lane, TH - 1), Hd - 1), inv_s, h);
+    const int jlo = __builtin_amdgcn_readfirstlane(txl.i0), jhi = __builtin_amdgcn_readlane(txl.i1, TW - 1);
+    const int ilo = __builtin_amdgcn_readfirstlane(tyl.i0), ihi = __builtin_amdgcn_readlane(tyl.i1, TH - 1);
+    const int nc = jhi - jlo + 1, nr = ihi - ilo + 1, nn = nc * nr;
+    // LDS (dwords): nodes float2[nn] | rows float2[nr][TW] (16-byte aligned) | y taps float4[TH]
+    const int o_rows = (2 * nn + 3) & ~3, o_yt = o_rows + 2 * nr * TW;
+    if (o_yt + 4 * TH > lds_dwords) return false;  // wave-uniform
+    {
+      float2* ln = reinterpret_cast<float2*>(lds);
+      float2* rows = reinterpret_cast<float2*>(lds + o_rows);
+      float4* ytab = reinterpret_cast<float4*>(lds + o_yt);
       for (int idx = lane; idx < nn; idx += 64) {
         const int r = idx / nc, c = idx - r * nc;
         ln[idx] = ((rl_gf2)nodes)[(size_t)(ilo + r) * w + jlo + c];
       }
+      if (lane < TH)
+        ytab[lane] = make_float4(__int_as_float((tyl.i0 - ilo) * TW), __int_as_float((tyl.i1 - ilo) * TW), tyl.w0, tyl.w1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    Tap tx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) tx[k] = tap_x(min(X + k, Wd - 1), inv_s, w);
-    if (in_lds) {  // two bodies, so that the LDS one keeps its address space (ds_read, not flat loads)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        tx[k].i0 -= jlo;
-        tx[k].i1 -= jlo;
-      }
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        Tap ty = tap_y(min(Yb + r * RW, Hd - 1), inv_s, h);
-        ty.i0 -= ilo;
-        ty.i1 -= ilo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float2 v = dense_at(ln, nc, tx[k], ty);
-          mv[r][2 * k] = __fmul_rn(v.x, scx);
-          mv[r][2 * k + 1] = __fmul_rn(v.y, scy);
+      if (lane < TW) {
+        const int c0 = txl.i0 - jlo, c1 = txl.i1 - jlo;
+        for (int r = 0; r < nr; ++r) {  // wave-uniform trip count (2..3 for a 25-px cell)
+          const float2 a = ln[r * nc + c0], b = ln[r * nc + c1];
+          rows[r * TW + lane] = make_float2(lerp2(a.x, txl.w0, b.x, txl.w1), lerp2(a.y, txl.w0, b.y, txl.w1));
         }
       }
-    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int lx4 = (lane % LX) * 4, ly = lane / LX;
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        const Tap ty = tap_y(min(Yb + r * RW, Hd - 1), inv_s, h);
+        const float4 yt = ytab[ly + r * RW];
+        const float4* t0 = reinterpret_cast<const float4*>(rows + __float_as_int(yt.x) + lx4);
+        const float4* t1 = reinterpret_cast<const float4*>(rows + __float_as_int(yt.y) + lx4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float2 v = dense_at((rl_gf2)nodes, w, tx[k], ty);
-          mv[r][2 * k] = __fmul_rn(v.x, scx);
-          mv[r][2 * k + 1] = __fmul_rn(v.y, scy);
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const float4 p = t0[k2], q = t1[k2];  // two pixels: (x, y, x, y)
+          mv[r][4 * k2 + 0] = __fmul_rn(lerp2(p.x, yt.z, q.x, yt.w), scx);
+          mv[r][4 * k2 + 1] = __fmul_rn(lerp2(p.y, yt.z, q.y, yt.w), scy);
+          mv[r][4 * k2 + 2] = __fmul_rn(lerp2(p.z, yt.z, q.z, yt.w), scx);
+          mv[r][4 * k2 + 3] = __fmul_rn(lerp2(p.w, yt.z, q.w, yt.w), scy);
         }
       }
     }
     __builtin_amdgcn_wave_barrier();  // the slice is re-used for the source window next
+    return true;
   }
 };
 
@@ -189,9 +198,12 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
                                                ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
                                                uint8_t* __restrict__ dst, ptrdiff_t ds, int X, int Yb) {
   constexpr int RW = 64 / LX;
+  // rolled loops: this rare path must not set the register budget (and with it the occupancy) of the kernel
+#pragma unroll 1
   for (int r = 0; r < RPT; ++r) {
     const int Y = Yb + r * RW;
     if (Y >= Hd) continue;
+#pragma unroll 1
     for (int k = 0; k < 4 && X + k < Wd; ++k) {
       const float2 m = ms.at(X + k, Y);
       uint8_t o[C];
@@ -203,8 +215,11 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 }
 
 // LDSW: bytes of LDS per wavefront (the source window budget).
+// Register budget: 8 wavefronts per SIMD (64 VGPRs) for one channel, where the 4 KB LDS slices allow that
+// many; 5 (96 VGPRs) for three and four channels, whose 8 KB slices admit no more.
+#define RL_WAVES_PER_SIMD(C) ((C) == 1 ? 8 : 5)
 template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
-__global__ __launch_bounds__(256) void remap_u8_wave_kernel(
+__global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C)) void remap_u8_wave_kernel(
     const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
     uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
@@ -215,9 +230,9 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   constexpr int TW = 4 * LX;    // tile width
   constexpr int PF = ((TW * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
   constexpr int MAXROWS = LDSW / PF;
-  constexpr int WIN_DW = (PF / 4) * MAXROWS + 2;
+  constexpr int WIN_DW = ((PF / 4) * MAXROWS + 2 + 3) & ~3;  // 16-byte multiples: b128 LDS accesses in MapNodes
 
-  __shared__ uint32_t win_all[4 * WIN_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t win_all[4 * WIN_DW];
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + wave;
@@ -228,7 +243,10 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
   const int X = bx * TW + lx4;
   const int Yb = by * TH + ly;  // row of pass r: Yb + r * RW
   float mv[RPT][8];
-  ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH);
+  if (!ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH)) {  // wave-uniform
+    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb);
+    return;
+  }
 
   // 1. + 2. (see the file comment for the clamp)
   // Quantisation without a float->int conversion: for |v| < 2^22, v + 1.5 * 2^23 rounds v to the nearest
@@ -273,11 +291,14 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
 
   // 3. stage: lanes cover (row, dword) pairs, 32 or 64 dwords per window row
   const int P4 = (wbytes + 3) >> 2, WB = W * C;
-  if (x0b >= 0 && x0b + 4 * P4 <= WB && mny >= 0 && mny + nrows <= H) {  // wave-uniform
+  if (x0b >= 0 && x0b + 4 * P4 <= WB && mny >= 0 && mny + nrows <= H && ss < (1 << 24)) {  // wave-uniform
     // window inside the image (all but the tiles on the page border): no per-dword tests, and the
     // loads of up to 8 window rows per lane are all in flight before the first one is written to LDS
     // (one memory round trip per tile instead of one per row pair)
-    constexpr int U = 8;
+#ifndef RL_STAGE_U
+#define RL_STAGE_U 8
+#endif
+    constexpr int U = RL_STAGE_U;
     const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
     const int r0 = lane >> sh;
     const uint8_t* pw = src + ((ptrdiff_t)mny * ss + x0b);  // wave-uniform base + 32-bit lane offsets
@@ -289,12 +310,12 @@ __global__ __launch_bounds__(256) void remap_u8_wave_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t row = (uint32_t)min(rb + r0 + u * rp, nrows - 1);
-          v[u] = *reinterpret_cast<const rl_u32u*>(pw + (row * ss32 + 4u * (uint32_t)c));
+          v[u] = *reinterpret_cast<const rl_u32u*>(pw + (__umul24(row, ss32) + 4u * (uint32_t)c));  // ss < 2^24
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int row = min(rb + r0 + u * rp, nrows - 1);
-          win[row * (PF / 4) + c] = v[u];
+          win[__mul24(row, PF / 4) + c] = v[u];
         }
       }
     }
