@@ -29,21 +29,25 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
   return OGD_OK;
 }
 
-// K2 launch: one wavefront per 64 x 8 output tile, four wavefronts per workgroup (ogd_remap_lds.h).
-constexpr int K2_LX = 16, K2_RPT = 2;
-constexpr int K2_TW = 4 * K2_LX, K2_TH = (64 / K2_LX) * K2_RPT;
+// Launch shapes (measured, tools/kbench): K2 proper streams the map, and 64 x 8 tiles keep its row
+// segments long (512 B per wavefront and row); the fused kernel streams nothing, and a square 32 x 32 tile
+// has the smaller source window per pixel and fewer x taps / lerped node rows to build per pixel.
+template <class MapSrc> struct TileShape { static constexpr int LX = 16, RPT = 2; };
+template <> struct TileShape<MapNodes> { static constexpr int LX = 8, RPT = 4; };
 
 template <int C, class MapSrc>
 static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
                          const MapSrc& ms, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
+  constexpr int LX = TileShape<MapSrc>::LX, RPT = TileShape<MapSrc>::RPT;
+  constexpr int TW = 4 * LX, TH = (64 / LX) * RPT;
   constexpr int LDSW = C == 1 ? 4096 : 8192;  // source window budget per wavefront
-  const int nbx = (Wd + K2_TW - 1) / K2_TW, nby = (Hd + K2_TH - 1) / K2_TH, nb = nbx * nby;
+  const int nbx = (Wd + TW - 1) / TW, nby = (Hd + TH - 1) / TH, nb = nbx * nby;
   const dim3 grid((nb + 3) / 4), block(256);
   if (interp == OGD_INTER_LINEAR)
-    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, K2_LX, K2_RPT, LDSW, MapSrc>), grid, block,
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, LX, RPT, LDSW, MapSrc>), grid, block,
                        0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
   else
-    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, K2_LX, K2_RPT, LDSW, MapSrc>), grid, block,
+    hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, LX, RPT, LDSW, MapSrc>), grid, block,
                        0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
 }
 

@@ -216,10 +216,14 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 
 // LDSW: bytes of LDS per wavefront (the source window budget).
 // Register budget: 8 wavefronts per SIMD (64 VGPRs) for one channel, where the 4 KB LDS slices allow that
-// many; 5 (96 VGPRs) for three and four channels, whose 8 KB slices admit no more.
-#define RL_WAVES_PER_SIMD(C) ((C) == 1 ? 8 : 5)
+// many (RL_W1B wavefronts, 80 VGPRs, for tiles of more than 8 pixels per lane, which would spill at 64);
+// 5 (96 VGPRs) for three and four channels, whose 8 KB slices admit no more.
+#ifndef RL_W1B
+#define RL_W1B 6
+#endif
+#define RL_WAVES_PER_SIMD(C, RPT) ((C) == 1 ? ((RPT) <= 2 ? 8 : RL_W1B) : 5)
 template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
-__global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C)) void remap_u8_wave_kernel(
+__global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
     const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
     uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;

@@ -1,7 +1,7 @@
 // kbench — kernel laboratory for K2 (remap): times candidate kernels against the library's
 // ogd_remap_u8_dev on one broadsheet page and checks that every candidate is bit-identical to it.
 // Development tool, not part of the product; winners are ported into origami_amd/csrc/ (the tile
-// shape the library launches is K2_LX / K2_RPT in ogd_remap.hip).
+// shapes the library launches are TileShape<> in ogd_remap.hip).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/kbench.hip \
 //         -Lorigami_amd/lib -logdewarp -Wl,-rpath,'$ORIGIN/../origami_amd/lib' -o tools/kbench
@@ -309,6 +309,28 @@ int main(int argc, char** argv) {
   WAVE_VARIANT(8, 2, 4096)
   WAVE_VARIANT(8, 4, 4096)
   WAVE_VARIANT(32, 2, 4096)
+#define FUSED_VARIANT(LX, RPT, LDSW)                                                                    \
+  {                                                                                                     \
+    const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
+    const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
+    const MapNodes mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, c.Hd, c.Wd};                   \
+    run(c, "fused LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                           \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapNodes>), dim3((nb + 3) / 4),     \
+                         dim3(256), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst,       \
+                         (ptrdiff_t)c.Wd, nbx2, nb);                                                    \
+    });                                                                                                 \
+  }
+  FUSED_VARIANT(16, 2, 4096)
+  FUSED_VARIANT(16, 4, 4096)
+  FUSED_VARIANT(16, 1, 4096)
+  FUSED_VARIANT(8, 2, 4096)
+  FUSED_VARIANT(8, 4, 4096)
+  FUSED_VARIANT(16, 2, 3072)
+  FUSED_VARIANT(4, 2, 4096)
+  FUSED_VARIANT(4, 4, 4096)
+  FUSED_VARIANT(8, 3, 4096)
+  FUSED_VARIANT(8, 4, 3072)
+  FUSED_VARIANT(8, 4, 5120)
 #define STREAM_TILE(LX, RPT)                                                                           \
   {                                                                                                     \
     const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
