@@ -33,7 +33,9 @@ typedef enum ogd_status {
   OGD_ERR_HIP = -2,      /* a HIP runtime call failed; ogd_last_error() has hipGetErrorString */
   OGD_ERR_NOMEM = -3,    /* host or device allocation failed */
   OGD_ERR_NODEVICE = -4, /* no gfx950 device visible */
-  OGD_ERR_UNSUPPORTED = -5 /* input outside the domain of a fast set-up path; take the general one */
+  OGD_ERR_UNSUPPORTED = -5, /* input outside the domain of a fast set-up path; take the general one */
+  OGD_ERR_RUNTIME = -6,    /* the algorithm failed where the reference raises RuntimeError (message alike) */
+  OGD_ERR_ASSERT = -7      /* a result the reference asserts on (NaN in the node grid) */
 } ogd_status;
 
 #define OGD_INTER_NEAREST 0 /* cv2.INTER_NEAREST */
@@ -176,6 +178,28 @@ int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int
  * (|x| < 2^20, multiples of 2^-40 — any float32 grid): the caller then runs Qhull as before. */
 int ogd_lattice_delaunay(const double* pts, int h, int w, int32_t* simplices, int64_t cap,
                          int64_t* n_simplices, int32_t* hull, int* n_hull, double* transform);
+
+/* ---- the march of the node grid on the device -------------------------------------
+ * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),
+ * :441-493 (grid_hv without the border extension), :176-263 (ShapelyBatchIntersections).
+ * A field is the angle interpolant lininterp(samples.points, samples.values, bounds) as an (inner, extra)
+ * pair of scalar triangulations (inner may be NULL), or the constant angle phi0 when extra is NULL (a field
+ * with <= 2 samples, ref: dewarp.py:112-113).  bounds = {0, 0, W, H} as passed to lininterp.
+ *
+ * ogd_march_shape: Field.estimate_extent of both fields -> n_cols (est_width), n_rows (est_height);
+ * OGD_ERR_RUNTIME "n_steps exceeded" like the reference.  The caller applies max_grid_size.
+ * ogd_march_grid: grid_h [n_rows][n_cols][2] float32 — as the reference leaves it, i.e. with the first and
+ * last node of rows 1.. pushed outwards by make_row_slice's in-place extension (dewarp.py:205-211) — and
+ * grid_hv [n_rows][n_cols][2] float32 before border extension.  num_slices = the reference's num_threads
+ * (columns are marched per slice with that slice's ray length, dewarp.py:448-483).  OGD_ERR_RUNTIME
+ * "failed to find intersection", OGD_ERR_ASSERT for NaN in grid_h. */
+int ogd_march_shape(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h,
+                    const ogd_tri* inner_v, const ogd_tri* extra_v, double phi0_v,
+                    const double* bounds, int W, int H, int s, int* n_rows, int* n_cols);
+int ogd_march_grid(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h,
+                   const ogd_tri* inner_v, const ogd_tri* extra_v, double phi0_v,
+                   const double* bounds, int s, int n_rows, int n_cols, int num_slices,
+                   float* grid_h, float* grid_hv);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,12 @@ SIGNATURES = {
 		c_void_p]),
 	"ogd_lattice_delaunay": (c_int, [
 		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
+	"ogd_march_shape": (c_int, [
+		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int,
+		POINTER(c_int), POINTER(c_int)]),
+	"ogd_march_grid": (c_int, [
+		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
+		c_void_p, c_void_p]),
 	"ogd_line_label_counts": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
 		c_void_p]),
@@ -108,10 +114,16 @@ def load():
 	return lib
 
 
+ERR_ASSERT = -7
+
+
 def check(status):
 	if status != 0:
 		msg = load().ogd_last_error()
-		raise OgdError(status, msg.decode("utf8", "replace") if msg else "unknown error")
+		msg = msg.decode("utf8", "replace") if msg else "unknown error"
+		if status == ERR_ASSERT:  # where the reference has an `assert`
+			raise AssertionError(msg)
+		raise OgdError(status, msg)
 
 
 def device_count():
@@ -400,3 +412,34 @@ def tri_rasterize(inner, extra, bounds, x0, y0, step, nx, ny, order="xy", dtype=
 		inner.handle if inner is not None else None, extra.handle, bp, float(x0), float(y0),
 		float(step), int(nx), int(ny), _ptr(out), sx, sy, int(dtype == np.float64)))
 	return out
+
+
+# ---- N2: the node-grid march ------------------------------------------------------------------------
+
+def _field_args(field):
+	"""field: (inner Triangulation or None, extra Triangulation) or a constant angle (float)."""
+	if isinstance(field, tuple):
+		inner, extra = field
+		return (inner.handle if inner is not None else None, extra.handle, 0.0)
+	return (None, None, float(field))
+
+
+def march_shape(field_h, field_v, bounds, width, height, cell):
+	"""(est_height, est_width) of GridFactory.grid_shape: both extent walks in one launch."""
+	b, bp = _bounds(bounds)
+	n_rows, n_cols = c_int(0), c_int(0)
+	check(load().ogd_march_shape(
+		*_field_args(field_h), *_field_args(field_v), bp, int(width), int(height), int(cell),
+		ctypes.byref(n_rows), ctypes.byref(n_cols)))
+	return n_rows.value, n_cols.value
+
+
+def march_grid(field_h, field_v, bounds, cell, n_rows, n_cols, num_slices):
+	"""grid_h (with the reference's in-place row-end extension) and grid_hv before border extension."""
+	b, bp = _bounds(bounds)
+	grid_h = np.empty((n_rows, n_cols, 2), dtype=np.float32)
+	grid_hv = np.empty((n_rows, n_cols, 2), dtype=np.float32)
+	check(load().ogd_march_grid(
+		*_field_args(field_h), *_field_args(field_v), bp, int(cell), int(n_rows), int(n_cols),
+		int(num_slices), _ptr(grid_h), _ptr(grid_hv)))
+	return grid_h, grid_hv

@@ -1,11 +1,13 @@
 """Dewarping with a vector field interpolated from scattered flow samples — the MI355X build of
 origami/core/dewarp.py (same classes, arguments, artifacts and errors).
 
-Host side (this file) keeps what is small and sequential: sample I/O, the Euler march of the node
-grid and its row intersections, artifact I/O.  Everything per pixel or per point runs in
-libogdewarp.so on the GPU:
+Host side (this file) keeps what is small: sample I/O, the border extension of the node grid (a few
+steps), artifact I/O.  Everything per pixel, per point or per marching step runs in libogdewarp.so
+on the GPU:
 
   Field.get / Transformer.__call__   -> K3  ogd_tri_eval[_ragged]   (ref: dewarp.py:119, 159)
+  GridFactory.grid_shape / grid_h / grid_hv -> ogd_march_shape, ogd_march_grid: every walk of the
+                                        march is one launch       (ref: dewarp.py:328-339, 421-493)
   Grid.points("full")                -> K1a ogd_grid_fill           (ref: dewarp.py:522-523)
   Dewarper.dewarped / dewarp_image   -> K2  ogd_dewarp_u8 (fused K1a+K2; ref: dewarp.py:612-614, 625-627)
   Grid.inverse                       -> ogd_grid_sample_bilinear    (ref: dewarp.py:565-567)
@@ -120,8 +122,15 @@ class Field:
 		self._size = size
 		if len(samples.points) <= 2:
 			self._interp = lambda pts: [phi0 for _ in pts]
+			self._device = float(phi0)
 		else:
 			self._interp = lininterp(samples.points, samples.values, (0, 0, size[0], size[1]))
+			self._device = self._interp.triangulations
+
+	@property
+	def device(self):
+		"""What the march kernels evaluate: the (inner, extra) triangulations, or the constant angle."""
+		return self._device
 
 	def get(self, pts):
 		angles = self._interp(pts)  # fp64 on the GPU
@@ -176,80 +185,6 @@ class Transformer:
 		return [out[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
 
 
-def extrapolate(a, b, x):
-	v = b - a
-	v /= np.linalg.norm(v)
-	return b + x * v
-
-
-def make_slices(n, k):
-	s = math.ceil(n / k)
-	for i in range(0, n, s):
-		yield slice(i, i + s)
-
-
-class BatchIntersections:
-	"""Nearest crossing of each marching ray with the next grid row, all rays of a row at once
-	(ref: dewarp.py:176-263, ShapelyBatchIntersections).  Closed-form segment/segment
-	intersections in fp64 replace the shapely STRtree queries."""
-
-	def __init__(self, grid_h, grid_res, k=3):
-		self.grid_h = grid_h
-		self.grid_res = grid_res
-		# The reference builds its per-row pieces from numpy views, which pushes the first and the
-		# last node of rows 1.. of grid_h `large` pixels outwards IN PLACE — the last node once per
-		# piece that reaches the row end (ref: dewarp.py:199-212).  Reproduced, since the step
-		# length below is derived from the modified rows.
-		grid_w = grid_h.shape[1]
-		large = grid_w * grid_res
-		n_tail = sum(1 for i in range(0, grid_w, k - 1) if i != 0 and i + k >= grid_w)
-		for gy in range(1, grid_h.shape[0]):
-			row = grid_h[gy]
-			row[0] = extrapolate(row[1], row[0], large)
-			for _ in range(n_tail):
-				row[-1] = extrapolate(row[-2], row[-1], large)
-		self._rows = grid_h.astype(np.float64)
-
-	def _hits(self, p0, p1, row):
-		# (n rays) x (m segments) parametric solve; closed intervals, parallel pairs skipped
-		r = (p1 - p0)[:, np.newaxis, :]
-		a = row[np.newaxis, :-1, :]
-		s = row[np.newaxis, 1:, :] - a
-		q = a - p0[:, np.newaxis, :]
-		den = r[..., 0] * s[..., 1] - r[..., 1] * s[..., 0]
-		with np.errstate(divide="ignore", invalid="ignore"):
-			t = (q[..., 0] * s[..., 1] - q[..., 1] * s[..., 0]) / den
-			u = (q[..., 0] * r[..., 1] - q[..., 1] * r[..., 0]) / den
-		ok = (den != 0) & (t >= 0) & (t <= 1) & (u >= 0) & (u <= 1)
-		x = p0[:, np.newaxis, 0] + t * r[..., 0]
-		y = p0[:, np.newaxis, 1] + t * r[..., 1]
-		return ok, x, y
-
-	def __call__(self, pts0, pts1, gy):
-		n_rows = self.grid_h.shape[0] - 1
-		p0 = pts0.astype(np.float64)
-		p1 = pts1.astype(np.float64)
-		todo = np.arange(len(pts0))
-		dy = 0
-		while len(todo):
-			ok, x, y = self._hits(p0[todo], p1[todo], self._rows[gy + 1 + dy])
-			dist = np.sqrt((x - p0[todo, np.newaxis, 0]) ** 2 + (y - p0[todo, np.newaxis, 1]) ** 2)
-			dist[~ok] = np.inf
-			best = np.argmin(dist, axis=1)
-			found = ok[np.arange(len(todo)), best]
-			sel = todo[found]
-			pts1[sel, 0] = x[found, best[found]]
-			pts1[sel, 1] = y[found, best[found]]
-			todo = todo[~found]
-			if len(todo):
-				if gy + dy + 1 < n_rows:
-					dy += 1
-				else:
-					i = int(todo[0])
-					raise RuntimeError("failed to find intersection for i=%d, n=%d, %s to %s." % (
-						i, len(pts0), pts0[i], pts1[i]))
-
-
 class GridFactory:
 	"""ref: dewarp.py:292-493."""
 
@@ -284,10 +219,15 @@ class GridFactory:
 			self._samples_v, (self._width, self._height), phi0=math.pi / 2))
 
 	@property
+	def _bounds(self):
+		return (0, 0, self._width, self._height)
+
+	@property
 	def grid_shape(self):
 		def make():
-			est_width = self.field_h.estimate_extent(0, self._width, step_size=self._grid_res)
-			est_height = self.field_v.estimate_extent(1, self._height, step_size=self._grid_res)
+			# both extent walks (Field.estimate_extent, ref: dewarp.py:124-140) in one launch
+			est_height, est_width = _shim.march_shape(
+				self.field_h.device, self.field_v.device, self._bounds, self._width, self._height, self._grid_res)
 			if max(est_width, est_height) > self._max_grid_size:
 				raise RuntimeError("estimated grid too big: (%d, %d)" % (est_height, est_width))
 			return est_height, est_width
@@ -327,50 +267,28 @@ class GridFactory:
 			raise ValueError(side)
 		return self._extend(grid_hv, 0, -1 if side == "top" else 1)
 
-	@property
-	def grid_h(self):
+	def _march(self):
+		"""grid_h and the core of grid_hv on the device: rows of grid_h are independent walks, and so are
+		the columns of grid_hv once grid_h exists (ogd_march_grid; ref: dewarp.py:421-483)."""
 		def make():
 			n_rows, n_cols = self.grid_shape
-			grid = np.zeros((n_rows, n_cols, 2), dtype=np.float32)
-			pts = np.zeros((n_rows, 2), dtype=np.float32)
-			pts[:, 1] = np.arange(n_rows) * self._grid_res
-			for gx in range(n_cols):
-				grid[:, gx, :] = pts
-				pts += self.field_h.get(pts) * self._grid_res
-			assert not np.any(np.isnan(grid))
-			return grid
-		return self._cached("grid_h", make)
+			return _shim.march_grid(
+				self.field_h.device, self.field_v.device, self._bounds, self._grid_res, n_rows, n_cols,
+				max(1, self._num_threads))
+		return self._cached("march", make)
+
+	@property
+	def grid_h(self):
+		"""As the reference leaves it once grid_hv has run: the first and the last node of rows 1..
+		are pushed outwards by make_row_slice's in-place extension (ref: dewarp.py:205-211)."""
+		return self._march()[0]
 
 	@property
 	def grid_hv(self):
 		return self._cached("grid_hv", self._make_grid_hv)
 
 	def _make_grid_hv(self):
-		grid_h = self.grid_h
-		field_v = self.field_v.get
-		grid_hv = np.zeros(grid_h.shape, dtype=np.float32)
-		intersections = BatchIntersections(grid_h, self._grid_res)
-
-		def compute_slice(sel):
-			rise = np.max(grid_h[1:, sel, 1], axis=1) - np.min(grid_h[:-1, sel, 1], axis=1)
-			max_dy = max(0, np.max(rise)) if len(rise) else 0
-			max_step_len = max_dy / math.cos(60 * (math.pi / 180))
-			pts0 = grid_h[0][sel]
-			for gy in range(grid_h.shape[0] - 1):
-				grid_hv[gy, sel, :] = pts0
-				pts1 = pts0 + field_v(pts0) * max_step_len
-				intersections(pts0, pts1, gy)
-				pts0 = pts1
-			grid_hv[-1, sel, :] = pts0
-
-		if self._num_threads < 2:
-			compute_slice(slice(0, grid_h.shape[1]))
-		else:
-			# the reference maps these column slices over a 2-thread pool (dewarp.py:474-483); they
-			# are independent, and sequential order keeps the single GPU stream busy without races
-			for sel in make_slices(grid_h.shape[1], self._num_threads):
-				compute_slice(sel)
-
+		grid_hv = self._march()[1]
 		grid_hv = self.extend_border_h(grid_hv, "left")
 		grid_hv = self.extend_border_h(grid_hv, "right")
 		grid_hv = self.extend_border_v(grid_hv, "top")

@@ -1,0 +1,109 @@
+"""The node-grid march on the device (ogd_march_shape / ogd_march_grid) against the CPU
+oracle's walk (oracle/dewarp.py:GridFactory, which follows origami/core/dewarp.py:328-493 step by step).
+
+Bar (BASELINE.json north_star): float grid within 1e-3 px.  Positions are float32 on both sides and every
+step is the same float32 multiply-add; the only difference is the last bit of cos / sin (numpy's float32
+routines vs fp64 cos rounded to float32), ~1e-6 px per step.  Grid shapes must be identical."""
+
+import math
+
+import numpy as np
+import PIL.Image
+import pytest
+
+from oracle import dewarp as odw
+from origami_amd import synth
+from origami_amd.dewarp import Geometry, Grid, GridFactory, Samples
+
+pytestmark = pytest.mark.gpu
+
+
+def _page(size):
+	class Page:
+		warped = PIL.Image.new("L", size)
+	return Page
+
+
+def _pair(rng, size, n_h, n_v, a=0.03, b=0.025, f1=1, f2=2):
+	warp = synth.Warp(size, a, b, f1, f2)
+	h, v = synth.flow_samples(rng, warp, n_h, n_v)
+	oh = odw.Samples(size, h.points, h.values)
+	ov = odw.Samples(size, v.points, v.values)
+	return h, v, oh, ov
+
+
+@pytest.mark.parametrize("size,cell,threads", [
+	((600, 800), 25, 2), ((1000, 700), 16, 2), ((900, 1300), 25, 1), ((1200, 1600), 25, 3)])
+def test_march_matches_oracle(gpu, size, cell, threads):
+	rng = np.random.default_rng(size[0] + cell)
+	h, v, oh, ov = _pair(rng, size, 150, 200)
+	fac = GridFactory(_page(size), h, v, grid_res=cell, num_threads=threads)
+	ofac = odw.GridFactory(size, oh, ov, grid_res=cell, num_threads=threads)
+	assert fac.grid_shape == ofac.grid_shape()
+	want_hv = ofac.grid_hv()
+	got_hv = fac.grid_hv
+	assert got_hv.shape == want_hv.shape and got_hv.dtype == np.float32
+	assert np.abs(got_hv - want_hv).max() < 1e-3
+	# grid_h as the reference leaves it (row ends of rows 1.. pushed outwards in place)
+	want_h = ofac.grid_h()
+	odw.extend_row_ends(want_h, cell)
+	got_h = fac.grid_h
+	assert got_h.shape == want_h.shape
+	assert np.abs(got_h[:, 1:-1] - want_h[:, 1:-1]).max() < 1e-3
+	# the pushed-out end nodes lie ~ n_cols * cell px away: same bar relative to that lever
+	assert np.abs(got_h[:, [0, -1]] - want_h[:, [0, -1]]).max() < 1e-2
+
+
+def test_march_broadsheet_page(gpu):
+	"""configs[1] geometry: 6000 x 8000 page, 1500 / 2000 flow samples, cell 25 (321 x 241 core nodes)."""
+	size = (6000, 8000)
+	rng = np.random.default_rng(11)
+	h, v, oh, ov = _pair(rng, size, 1500, 2000, a=0.03, b=0.02)
+	grid = Grid.create(_page(size), h, v, grid_res=25)
+	want = odw.Grid.create(size, oh, ov, grid_res=25)
+	hv = grid.points("sample")
+	assert hv.shape == want.hv.shape
+	assert np.abs(hv - want.hv).max() < 1e-3
+
+
+def test_constant_fields_give_a_regular_grid(gpu):
+	"""<= 2 samples per direction: constant angles 0 and pi/2 (ref: dewarp.py:112-113, 318-326)."""
+	size = (500, 400)
+	empty = Samples(Geometry(*size))
+	fac = GridFactory(_page(size), empty, empty, grid_res=25)
+	ofac = odw.GridFactory(size, odw.Samples(size), odw.Samples(size), grid_res=25)
+	assert fac.grid_shape == ofac.grid_shape()
+	got, want = fac.grid_hv, ofac.grid_hv()
+	assert got.shape == want.shape
+	assert np.abs(got - want).max() < 1e-3
+	# rows are horizontal up to float32(cos(pi / 2)) * 25 px per step
+	assert np.abs(got[:, :, 1] - got[:, :1, 1]).max() < 1e-3
+
+
+def test_grid_too_big_raises_like_the_reference(gpu):
+	size = (600, 800)
+	rng = np.random.default_rng(3)
+	h, v, _, _ = _pair(rng, size, 100, 100)
+	fac = GridFactory(_page(size), h, v, grid_res=25, max_grid_size=20)
+	with pytest.raises(RuntimeError, match="estimated grid too big"):
+		fac.grid_hv
+
+
+def test_walk_that_never_leaves_the_page_raises(gpu):
+	"""A horizontal field that points upwards never reaches the right edge: estimate_extent gives up after
+	2 * (1 + width) steps (ref: dewarp.py:131-139)."""
+	size = (300, 200)
+	up = Samples(Geometry(*size))
+	rng = np.random.default_rng(5)
+	pts = rng.uniform([0, 0], size, size=(40, 2))
+	up.extend(list(pts), [math.pi / 2] * len(pts))  # "horizontal" flow that runs along y
+	fac = GridFactory(_page(size), up, up, grid_res=25)
+	with pytest.raises(RuntimeError, match="n_steps exceeded"):
+		fac.grid_shape
+
+
+def test_march_entry_points_validate_arguments(gpu):
+	with pytest.raises(gpu.OgdError):
+		gpu.march_grid(0.0, math.pi / 2, (0, 0, 100, 100), 25, 1, 10, 2)  # one row: nothing to march
+	with pytest.raises(gpu.OgdError):
+		gpu.march_shape(0.0, math.pi / 2, (0, 0, 100, 100), 100, 100, 0)
