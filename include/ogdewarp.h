@@ -119,6 +119,11 @@ int ogd_tri_eval_ragged(const ogd_tri* inner, const ogd_tri* extra, const double
 int ogd_tri_eval_ragged_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
                             const double* d_q, const int64_t* d_offsets, int nrings,
                             double* d_out, void* stream);
+/* The quadratic part of the validity test the stage applies to every warped polygon ring
+ * (ref: origami/batch/detect/dewarp.py:35, shapely `geom.is_valid`): flags[r] = 1 if two non-adjacent
+ * segments of closed ring r (points offsets[r] .. offsets[r+1]-1, first = last) touch or cross, else 0.
+ * One wavefront per ring, exact orientation signs in fp64. */
+int ogd_rings_self_cross(const double* q, const int64_t* offsets, int nrings, uint8_t* flags);
 /* Dense variant on the lattice (x0 + ix*step, y0 + iy*step), ix < nx, iy < ny; component k of
  * lattice point (ix, iy) is written to out[ix*stride_x + iy*stride_y + k] (strides in elements).
  * out_f64 = 0: float32 output, 1: float64.  ref: origami/core/lingrid.py:257-277. */
@@ -178,6 +183,14 @@ int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int
  * (|x| < 2^20, multiples of 2^-40 — any float32 grid): the caller then runs Qhull as before. */
 int ogd_lattice_delaunay(const double* pts, int h, int w, int32_t* simplices, int64_t cap,
                          int64_t* n_simplices, int32_t* hull, int* n_hull, double* transform);
+
+/* ---- WKT coordinate text (host code) ---------------------------------------------------------------
+ * ref: origami/batch/detect/dewarp.py:39 (`geom.wkt`: shapely -> GEOS WKTWriter, trim, 16 significant digits).
+ * Ring r (points offsets[r] .. offsets[r+1]-1 of pts [n][2] float64) becomes "(x y, x y, ...)" at
+ * out[text_offsets[r] .. text_offsets[r+1]); numbers as printf("%.16g"), "nan", "inf", "-inf".
+ * cap >= 52 * n + 2 * nrings bytes is always enough.  No terminating NUL is written. */
+int ogd_wkt_ring_text(const double* pts, const int64_t* offsets, int nrings, char* out, int64_t cap,
+                      int64_t* text_offsets);
 
 /* ---- the march of the node grid on the device -------------------------------------
  * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),

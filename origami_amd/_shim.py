@@ -67,6 +67,7 @@ SIGNATURES = {
 	"ogd_tri_eval_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 	"ogd_tri_eval_ragged_dev": (c_int, [
 		c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+	"ogd_rings_self_cross": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
 	"ogd_tri_rasterize": (c_int, [
 		c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int, c_int, c_void_p, c_int64,
 		c_int64, c_int]),
@@ -83,6 +84,7 @@ SIGNATURES = {
 		c_void_p]),
 	"ogd_lattice_delaunay": (c_int, [
 		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
+	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
 	"ogd_march_shape": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int,
 		POINTER(c_int), POINTER(c_int)]),
@@ -392,6 +394,18 @@ def tri_eval_ragged(inner, extra, bounds, q, offsets):
 	return out
 
 
+def rings_self_cross(rings):
+	"""One flag per closed ring: do two of its non-adjacent segments touch or cross (wavefront per ring)."""
+	if not rings:
+		return np.zeros(0, dtype=bool)
+	offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+	np.cumsum([len(r) for r in rings], out=offsets[1:])
+	flat = _c(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]), np.float64)
+	flags = np.zeros(len(rings), dtype=np.uint8)
+	check(load().ogd_rings_self_cross(_ptr(flat), _ptr(offsets), len(rings), _ptr(flags)))
+	return flags.astype(bool)
+
+
 def tri_rasterize(inner, extra, bounds, x0, y0, step, nx, ny, order="xy", dtype=np.float64):
 	"""Values on the lattice (x0 + i*step, y0 + j*step); order "xy" -> (nx, ny, nv) like
 	lingrid's mgrid layout, "yx" -> (ny, nx, nv) image layout."""
@@ -443,3 +457,21 @@ def march_grid(field_h, field_v, bounds, cell, n_rows, n_cols, num_slices):
 		*_field_args(field_h), *_field_args(field_v), bp, int(cell), int(n_rows), int(n_cols),
 		int(num_slices), _ptr(grid_h), _ptr(grid_hv)))
 	return grid_h, grid_hv
+
+
+# ---- WKT coordinate text (host code in the library) -------------------------------------------------
+
+def wkt_ring_texts(rings):
+	"""["(x y, x y, ...)", ...] for a list of (n, 2) arrays, formatted like GEOS' WKTWriter ("%.16g")."""
+	if not rings:
+		return []
+	offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+	np.cumsum([len(r) for r in rings], out=offsets[1:])
+	flat = _c(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]), np.float64)
+	cap = 52 * int(offsets[-1]) + 2 * len(rings)
+	buf = ctypes.create_string_buffer(cap)
+	text_offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+	check(load().ogd_wkt_ring_text(
+		_ptr(flat), _ptr(offsets), len(rings), ctypes.cast(buf, c_void_p), cap, _ptr(text_offsets)))
+	raw = buf.raw
+	return [raw[a:b].decode("ascii") for a, b in zip(text_offsets[:-1], text_offsets[1:])]

@@ -14,8 +14,9 @@ from pathlib import Path
 
 import click
 
+from ... import _shim
 from ...dewarp import Grid, Samples
-from ...geometry import parse_wkt
+from ...geometry import parse_wkt, to_wkt_many
 from ..core.io import Artifact, Input, Output, Stage
 from ..core.processor import Processor
 
@@ -36,10 +37,14 @@ def dewarped_contours(warped, transformer, min_areas):
 	# one ragged launch for all rings of the page
 	rings = [r for g in geoms for r in g.rings]
 	warped_rings = transformer.transform_rings(rings)
+	# ... and one for the quadratic part of every ring's validity test (ref: dewarp.py:35)
+	crossing = _shim.rings_self_cross(warped_rings)
 	k = 0
+	kept_names, kept = [], []
 	for name, warped_geom in zip(names, geoms):
 		n = len(warped_geom.rings)
 		geom = warped_geom.with_rings(warped_rings[k:k + n])
+		ring_flags = crossing[k:k + n]
 		k += n
 		path = tuple(name.rsplit(".", 1)[0].split("/"))
 		if geom.is_empty or geom.area < min_areas.get(path[0], 0):
@@ -47,11 +52,14 @@ def dewarped_contours(warped, transformer, min_areas):
 			continue
 		if geom.geom_type not in ("Polygon", "LineString"):
 			logging.error("dewarped contour %s is %s" % (name, geom.geom_type))
-		if not geom.is_valid:
+		if not geom.valid_given(ring_flags):
 			# the reference repairs with shapely's buffer(0) (GEOS); this build has no polygon
 			# repair and passes the geometry on as it is
 			logging.error("invalid geom %s", name)
-		yield name, geom.wkt.encode("utf8")
+		kept_names.append(name)
+		kept.append(geom)
+	for name, text in zip(kept_names, to_wkt_many(kept)):
+		yield name, text.encode("utf8")
 
 
 class DewarpProcessor(Processor):

@@ -139,6 +139,47 @@ __global__ __launch_bounds__(RS_TW* RS_TH) void tri_rasterize_kernel(
   }
 }
 
+// Ring validity, the O(n^2) part (ref: origami/batch/detect/dewarp.py:35, `geom.is_valid`: a warped polygon
+// ring must not touch or cross itself).  One wavefront per ring: segment i is wave-uniform, the lanes take
+// the segments j >= i + 2 (the closing pair (0, n-1) is adjacent); orientation signs in fp64 without FMA
+// contraction, the arithmetic of origami_amd/geometry.py:_segments_cross.
+__device__ __forceinline__ int orient_sign(double px, double py, double qx, double qy, double sx, double sy) {
+  const double v = __dsub_rn(__dmul_rn(qx - px, sy - py), __dmul_rn(qy - py, sx - px));
+  return (v > 0.0) - (v < 0.0);
+}
+
+__device__ __forceinline__ bool on_segment(double px, double py, double qx, double qy, double sx, double sy, int o) {
+  return o == 0 && fmin(px, qx) <= sx && sx <= fmax(px, qx) && fmin(py, qy) <= sy && sy <= fmax(py, qy);
+}
+
+__global__ __launch_bounds__(256) void rings_self_cross_kernel(const double2* __restrict__ q,
+                                                               const int64_t* __restrict__ offsets, int nrings,
+                                                               uint8_t* __restrict__ flags) {
+  const int ring = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (ring >= nrings) return;
+  const int lane = threadIdx.x & 63;
+  const double2* r = q + offsets[ring];
+  const int n = (int)(offsets[ring + 1] - offsets[ring]) - 1;  // segments of the closed ring
+  bool hit = false;
+  if (n >= 3) {
+    for (int i = 0; i + 2 < n; ++i) {
+      const double2 a = r[i], b = r[i + 1];
+      const int jend = i == 0 ? n - 1 : n;  // segment n-1 is adjacent to segment 0
+      for (int j = i + 2 + lane; j < jend; j += 64) {
+        const double2 c = r[j], d = r[j + 1];
+        const int o1 = orient_sign(a.x, a.y, b.x, b.y, c.x, c.y), o2 = orient_sign(a.x, a.y, b.x, b.y, d.x, d.y);
+        const int o3 = orient_sign(c.x, c.y, d.x, d.y, a.x, a.y), o4 = orient_sign(c.x, c.y, d.x, d.y, b.x, b.y);
+        const bool proper = o1 * o2 < 0 && o3 * o4 < 0;
+        const bool touch = on_segment(a.x, a.y, b.x, b.y, c.x, c.y, o1) || on_segment(a.x, a.y, b.x, b.y, d.x, d.y, o2) ||
+                           on_segment(c.x, c.y, d.x, d.y, a.x, a.y, o3) || on_segment(c.x, c.y, d.x, d.y, b.x, b.y, o4);
+        hit = hit || proper || touch;
+      }
+    }
+  }
+  const bool any = __any(hit);
+  if (lane == 0) flags[ring] = any ? 1 : 0;
+}
+
 // ---- host: records + bucket grid ----------------------------------------------------------------
 
 static inline double edge_fn(double ax, double ay, double bx, double by, double px, double py) {
@@ -387,6 +428,28 @@ int ogd_tri_eval_ragged(const ogd_tri* inner, const ogd_tri* extra, const double
   OGD_TRY(ogd_tri_eval_ragged_dev(inner, extra, bounds, dq.as<double>(), doff.as<int64_t>(), nrings,
                                   dout.as<double>(), nullptr));
   OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_rings_self_cross(const double* q, const int64_t* offsets, int nrings, uint8_t* flags) {
+  OGD_REQUIRE(nrings >= 0, "negative ring count");
+  if (nrings == 0) return OGD_OK;
+  OGD_REQUIRE(q && offsets && flags, "null pointer");
+  OGD_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+  for (int r = 0; r < nrings; ++r)
+    OGD_REQUIRE(offsets[r + 1] >= offsets[r], "offsets must be non-decreasing (ring %d)", r);
+  const int64_t nq = offsets[nrings];
+  OGD_TRY(ensure_device());
+  DevBuf dq, doff, dfl;
+  OGD_TRY(dq.alloc((size_t)nq * 2 * sizeof(double)));
+  OGD_TRY(doff.alloc((size_t)(nrings + 1) * sizeof(int64_t)));
+  OGD_TRY(dfl.alloc((size_t)nrings));
+  if (nq) OGD_HIP(hipMemcpy(dq.p, q, (size_t)nq * 2 * sizeof(double), hipMemcpyHostToDevice));
+  OGD_HIP(hipMemcpy(doff.p, offsets, (size_t)(nrings + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(rings_self_cross_kernel, dim3((unsigned)((nrings + 3) / 4)), dim3(256), 0, nullptr,
+                     dq.as<double2>(), doff.as<int64_t>(), nrings, dfl.as<uint8_t>());
+  OGD_TRY(check_launch("rings_self_cross_kernel"));
+  OGD_HIP(hipMemcpy(flags, dfl.p, (size_t)nrings, hipMemcpyDeviceToHost));
   return OGD_OK;
 }
 

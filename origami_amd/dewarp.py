@@ -189,7 +189,9 @@ class GridFactory:
 	"""ref: dewarp.py:292-493."""
 
 	def __init__(self, page, samples_h, samples_v, grid_res=25, max_grid_size=1000, num_threads=2):
-		size = page.warped.size
+		# the page's size without decoding its pixels where the page object can tell (origami_amd.page.Page);
+		# any object with a `warped` image works as in the reference (ref: dewarp.py:299)
+		size = page.size(False) if callable(getattr(page, "size", None)) else page.warped.size
 		self._width = size[0]
 		self._height = size[1]
 		self._grid_res = grid_res

@@ -13,6 +13,7 @@ import numpy as np
 
 _NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?|[-+]?(?:nan|inf)"
 _RING = re.compile(r"\(([^()]*)\)")
+_PLAIN = re.compile(r"^[-+0-9.eE,\s]*$")
 
 
 class Geom:
@@ -41,12 +42,19 @@ class Geom:
 
 	@property
 	def is_valid(self):
+		return self.valid_given(None)
+
+	def valid_given(self, crossing):
+		"""is_valid with the quadratic part precomputed: crossing[k] tells whether ring k touches or crosses
+		itself (the batch stage gets these flags for all rings of a page from one launch of
+		ogd_rings_self_cross); None computes them here."""
 		if self.is_empty:
 			return True
 		if self.geom_type == "LineString":
 			r = self.rings[0]
 			return len(r) >= 2 and bool(np.all(np.isfinite(r))) and not bool(np.all(r == r[0]))
-		return all(_ring_is_valid(r) for r in self.rings) and _holes_inside(self.rings)
+		flags = crossing if crossing is not None else [None] * len(self.rings)
+		return all(_ring_is_valid(r, c) for r, c in zip(self.rings, flags)) and _holes_inside(self.rings)
 
 	def transform(self, fn):
 		"""shapely.ops.transform: fn(xs, ys) -> (xs', ys') applied ring by ring."""
@@ -103,7 +111,7 @@ def _segments_cross(r):
 	return bool(np.any((proper | touch) & non_adjacent))
 
 
-def _ring_is_valid(r):
+def _ring_is_valid(r, crosses=None):
 	if len(r) < 4 or not np.all(np.isfinite(r)):
 		return False
 	if not np.array_equal(r[0], r[-1]):
@@ -112,7 +120,7 @@ def _ring_is_valid(r):
 		return False
 	if ring_area_signed(r) == 0:
 		return False
-	return not _segments_cross(r)
+	return not (_segments_cross(r) if crosses is None else crosses)
 
 
 def _point_in_ring(p, r):
@@ -146,15 +154,18 @@ def parse_wkt(text):
 		parts = _RING.findall(body[1:-1])
 	rings = []
 	for part in parts:
-		nums = re.findall(_NUM, part, re.IGNORECASE)
-		n_coord = len(part.split(",")) if part.strip() else 0
+		n_coord = part.count(",") + 1 if part.strip() else 0
 		if n_coord == 0:
 			rings.append(np.empty((0, 2)))
 			continue
+		if _PLAIN.match(part):  # digits, signs, exponents, blanks, commas: numpy's text parser (strtod)
+			nums = np.fromstring(part.replace(",", " "), dtype=np.float64, sep=" ")
+		else:  # nan / inf spellings and anything unusual
+			nums = np.array(re.findall(_NUM, part, re.IGNORECASE), dtype=np.float64)
 		dim = len(nums) // n_coord
 		if dim < 2 or dim * n_coord != len(nums):
 			raise ValueError("malformed WKT coordinates")
-		rings.append(np.array(nums, dtype=np.float64).reshape(n_coord, dim)[:, :2])
+		rings.append(nums.reshape(n_coord, dim)[:, :2])
 	return Geom(kind, rings)
 
 
@@ -179,3 +190,19 @@ def to_wkt(geom):
 	if geom.is_empty:
 		return "LINESTRING EMPTY"
 	return "LINESTRING " + _ring_text(geom.rings[0])
+
+
+def to_wkt_many(geoms):
+	"""WKT of many geometries with the coordinate text of ALL their rings formatted by one call into
+	libogdewarp (ogd_wkt_ring_text, host code: what GEOS' C++ WKTWriter is to the reference)."""
+	from . import _shim
+	texts = iter(_shim.wkt_ring_texts([r for g in geoms if not g.is_empty for r in g.rings]))
+	out = []
+	for g in geoms:
+		if g.is_empty:
+			out.append(to_wkt(g))
+		elif g.geom_type == "Polygon":
+			out.append("POLYGON (" + ", ".join(next(texts) for _ in g.rings) + ")")
+		else:
+			out.append("LINESTRING " + next(texts))
+	return out

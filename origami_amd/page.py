@@ -38,37 +38,46 @@ def _find_image_path(path):
 class Page:
 	def __init__(self, path, dewarping_transform=None):
 		path = _find_image_path(path)
-		self._warped = PIL.Image.open(str(path)).convert("L")
+		# The reference decodes and converts here (ref: page.py:84).  PIL reads only the header on open(),
+		# and the dewarp stage asks a warped page for nothing but its size, so the pixels are decoded on
+		# first use: 0.19 s per broadsheet PNG that this stage never spends.
+		self._opened = PIL.Image.open(str(path))
+		self._warped = None
 		self._device_page = None
-		if dewarping_transform is not None:
-			self._dewarper = Dewarper(self._warped, dewarping_transform)
-		else:
-			self._dewarper = None
+		self._grid = dewarping_transform
+		self._dewarper = None
 
 	@property
 	def warped(self):
+		if self._warped is None:
+			self._warped = self._opened.convert("L")
+			self._opened = None
 		return self._warped
 
 	@property
 	def dewarped(self):
-		return self._dewarper.dewarped if self._dewarper is not None else None
+		return self.dewarper.dewarped if self._grid is not None else None
 
 	def size(self, dewarped):
-		return (self.dewarped if dewarped else self._warped).size
+		if dewarped:
+			return self.dewarped.size
+		return self._warped.size if self._warped is not None else self._opened.size
 
 	def geometry(self, dewarped):
 		return Geometry(*self.size(dewarped))
 
 	def pixels(self, dewarped):
-		return np.array(self.dewarped if dewarped else self._warped)
+		return np.array(self.dewarped if dewarped else self.warped)
 
 	@property
 	def dewarper(self):
+		if self._dewarper is None and self._grid is not None:
+			self._dewarper = Dewarper(self.warped, self._grid)
 		return self._dewarper
 
 	@property
 	def device_page(self):
 		"""The warped page resident in device memory; line images are cut from it (block.py:255)."""
 		if self._device_page is None:
-			self._device_page = _shim.DevicePage(np.array(self._warped))
+			self._device_page = _shim.DevicePage(np.array(self.warped))
 		return self._device_page

@@ -119,10 +119,17 @@ def write_page_dir(root, name, rng, size=(2400, 3400), n_h=300, n_v=500, n_regio
 		n_separators=12, warp=None, label_size=(1280, 2400)):
 	"""Writes `<root>/<name>.png` and the `<name>.out/` inputs of the dewarp stage
 	(SURVEY.md Appendix B): segment.zip, contours.0.zip, flow.zip."""
-	W, H = size
-	warp = warp or Warp.random(rng, size)
 	page_path = root / ("%s.png" % name)
 	PIL.Image.fromarray(text_page(rng, size)).save(page_path)
+	write_page_inputs(page_path, rng, size, n_h, n_v, n_regions, n_separators, warp, label_size)
+	return page_path
+
+
+def write_page_inputs(page_path, rng, size=(2400, 3400), n_h=300, n_v=500, n_regions=60,
+		n_separators=12, warp=None, label_size=(1280, 2400)):
+	"""The `<name>.out/` inputs of the dewarp stage for an existing page image of `size`."""
+	W, H = size
+	warp = warp or Warp.random(rng, size)
 	out = page_path.with_suffix(".out")
 	out.mkdir(exist_ok=True)
 

@@ -243,3 +243,26 @@ def test_tri_rasterize_equals_point_queries(gpu):
 	xs, ys = np.mgrid[0:300, 0:200]
 	q = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.float64)
 	np.testing.assert_array_equal(dense.ravel(), fac.interpolator(q))
+
+
+def test_rings_self_cross_matches_host_geometry(gpu):
+	"""ogd_rings_self_cross (wavefront per ring) against the numpy restatement in origami_amd/geometry.py:
+	simple rings, bow-ties, rings that touch themselves at a vertex or along an edge, tiny rings."""
+	from origami_amd import geometry
+	rng = np.random.default_rng(42)
+	rings = synth.polygon_rings(rng, (3000, 4000), 300, mu=30)
+	for _ in range(100):  # random vertex order: most of these cross themselves
+		p = rng.integers(0, 50, size=(int(rng.integers(3, 90)), 2)).astype(np.float64)
+		rings.append(np.vstack([p, p[:1]]))
+	rings.append(np.array([[0, 0], [4, 4], [4, 0], [0, 4], [0, 0]], dtype=np.float64))  # bow-tie
+	rings.append(np.array([[0, 0], [4, 0], [4, 4], [2, 0], [0, 4], [0, 0]], dtype=np.float64))  # touches an edge
+	rings.append(np.array([[0, 0], [4, 0], [2, 2], [4, 4], [0, 4], [2, 2], [0, 0]], dtype=np.float64))  # vertex twice
+	rings.append(np.array([[0, 0], [1, 0], [0, 1], [0, 0]], dtype=np.float64))  # triangle
+	rings.append(np.array([[0, 0], [1, 1], [0, 0]], dtype=np.float64))  # degenerate: two segments
+	rings.append(np.array([[0, 0], [4, 0], [4, 4], [0, 4], [0, 0]], dtype=np.float64))
+	got = gpu.rings_self_cross(rings)
+	want = np.array([geometry._segments_cross(r) for r in rings])
+	assert got.dtype == bool and got.shape == want.shape
+	np.testing.assert_array_equal(got, want)
+	assert want[:300].sum() == 0 and want[300:400].sum() > 50
+	assert len(gpu.rings_self_cross([])) == 0

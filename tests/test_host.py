@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import lingrid as olin
-from origami_amd import geometry, synth
+from origami_amd import _shim, geometry, synth
 from origami_amd.dewarp import Geometry, Grid, Samples
 from origami_amd.lingrid import InterpolatorFactory
 
@@ -119,6 +119,29 @@ def test_wkt_round_trip_and_number_format():
 	assert geometry.format_number(1 / 3) == "0.3333333333333333"
 	assert geometry.format_number(4687.500000000001) == "4687.500000000001"
 	assert geometry.parse_wkt("POLYGON EMPTY").is_empty
+
+
+def test_native_wkt_writer_equals_python_formatting():
+	"""ogd_wkt_ring_text (host code in libogdewarp, no GPU needed) against "%.16g" % v."""
+	rng = np.random.default_rng(0)
+	rings = [rng.normal(0, 3000, (n, 2)) for n in (5, 1, 0, 400)]
+	rings.append(np.array([[1.0, 2.5], [1e-7, -3e22], [np.nan, np.inf], [-np.inf, 0.1], [123456789.123456789, 1 / 3]]))
+	rings.append(np.round(rng.normal(0, 1000, (30, 2))))  # integer coordinates print without a fraction
+	rings.append(rng.normal(0, 1, (50, 2)) * 10.0 ** rng.integers(-12, 12, (50, 2)))
+	assert _shim.wkt_ring_texts(rings) == [geometry._ring_text(r) for r in rings]
+	assert _shim.wkt_ring_texts([]) == []
+	geoms = [
+		geometry.parse_wkt("POLYGON ((0 0, 10.5 0, 10.5 7.25, 0 7.25, 0 0), (2 2, 3 2, 3 3, 2 2))"),
+		geometry.parse_wkt("POLYGON EMPTY"), geometry.parse_wkt("LINESTRING (1.5 2, 3 4.125, 1e3 -2.5e-3)"),
+		geometry.Geom("Polygon", [rings[3]])]
+	assert geometry.to_wkt_many(geoms) == [g.wkt for g in geoms]
+	# parse: numpy's text parser and the regex path agree, also on nan / inf spellings and 3-D input
+	g = geometry.parse_wkt("LINESTRING (nan 1, inf -2, -inf 3e4)")
+	assert np.isnan(g.rings[0][0, 0]) and g.rings[0][1, 0] == np.inf and g.rings[0][2].tolist() == [-np.inf, 3e4]
+	z = geometry.parse_wkt("POLYGON Z ((0 0 1, 1 0 1, 1 1 1, 0 0 1))")
+	assert z.rings[0].tolist() == [[0, 0], [1, 0], [1, 1], [0, 0]]
+	with pytest.raises(ValueError):
+		geometry.parse_wkt("LINESTRING (1 2, 3)")
 
 
 def test_validity_and_transform():
