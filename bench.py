@@ -93,11 +93,14 @@ def build_workload(torch, shim, dev, n_pages, rank):
 	for p in range(n_pages):
 		prng = np.random.default_rng(2000 * 2000 + p)
 		rings = synth.polygon_rings(prng, PAGE, N_POLYGONS, integer_scale=W / 1280)
-		offsets = np.zeros(len(rings) + 1, dtype=np.int64)
-		np.cumsum([len(r) for r in rings], out=offsets[1:])
+		ring_off = np.zeros(len(rings) + 1, dtype=np.int64)
+		np.cumsum([len(r) for r in rings], out=ring_off[1:])
+		# one wavefront per ring piece of <= 64 vertices, as the host entry point does (include/ogdewarp.h)
+		offsets = np.unique(np.concatenate(
+			[np.arange(a, b, 64) for a, b in zip(ring_off[:-1], ring_off[1:])] + [ring_off[-1:]])).astype(np.int64)
 		flat = np.concatenate(rings)
 		polys.append(dict(
-			rings=rings, n=len(flat), nrings=len(rings),
+			rings=rings, n=len(flat), nrings=len(offsets) - 1,
 			q=torch.from_numpy(flat).to(dev), off=torch.from_numpy(offsets).to(dev),
 			out=torch.empty((len(flat), 2), dtype=torch.float64, device=dev)))
 
@@ -209,7 +212,7 @@ def cpu_baseline(wl, threads, budget_s=12.0):
 	return dict(
 		value=round(mp / spent, 2), unit="MP/s", cores=threads, kind="port",
 		sample="%d pages 6000x8000 gray of the batch in %.1f s: dense grid + remap %.2f s (C/OpenMP oracle, %d threads) + %d contour rings/page %.2f s (scipy, 1 thread)" % (
-			n, spent, t_pix, threads, wl["polys"][0]["nrings"], t_pts))
+			n, spent, t_pix, threads, len(wl["polys"][0]["rings"]), t_pts))
 
 
 def timed_steps(step, steps, warmup, sync, dist, world, device, between=None):

@@ -113,7 +113,10 @@ int ogd_tri_eval(const ogd_tri* inner, const ogd_tri* extra, const double* bound
 int ogd_tri_eval_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
                      const double* d_q, int64_t nq, double* d_out, void* stream);
 /* Ragged batch: ring r owns points offsets[r] .. offsets[r+1]-1; one wavefront per ring.
- * ref: origami/batch/detect/dewarp.py:26 (shapely.ops.transform -> one Transformer call per ring). */
+ * ref: origami/batch/detect/dewarp.py:26 (shapely.ops.transform -> one Transformer call per ring).
+ * The host form cuts rings longer than 64 vertices into 64-vertex pieces (one wavefront each), so that the
+ * launch does not wait for its longest ring; a caller of the _dev form gets the same by passing the piece
+ * boundaries as offsets (any partition of the points into intervals is valid). */
 int ogd_tri_eval_ragged(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,
                         const double* q, const int64_t* offsets, int nrings, double* out);
 int ogd_tri_eval_ragged_dev(const ogd_tri* inner, const ogd_tri* extra, const double* bounds,

@@ -30,20 +30,33 @@ for heavy, n_rings in ((False, 400), (True, 5000)):
 	out = torch.empty((len(q), 2), dtype=torch.float64, device=dev)
 	stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-	def launch():
+	# the same points with rings longer than 64 vertices cut into 64-vertex pieces (one wavefront each)
+	cut = np.unique(np.concatenate([np.arange(a, b, 64) for a, b in zip(off[:-1], off[1:])] + [off[-1:]]))
+	o64 = torch.from_numpy(cut.astype(np.int64)).to(dev)
+
+	def launch_rings():
 		_shim.check(lib.ogd_tri_eval_ragged_dev(
 			inner.handle, extra.handle, bounds.ctypes.data, q.data_ptr(), o.data_ptr(), n_rings, out.data_ptr(), stream))
 
-	for _ in range(3):
-		launch()
-	torch.cuda.synchronize()
-	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-	e0.record()
-	for _ in range(20):
-		launch()
-	e1.record()
-	torch.cuda.synchronize()
-	ms = e0.elapsed_time(e1) / 20
-	n = len(q)
-	print("K3 %s: %d rings, %d points: %.1f us  %.2f Gpoints/s  (%.1f GB/s of 32 B/point)" % (
-		"heavy" if heavy else "normal", n_rings, n, ms * 1e3, n / ms / 1e6, n * 32 / ms / 1e6))
+	def launch_pieces():
+		_shim.check(lib.ogd_tri_eval_ragged_dev(
+			inner.handle, extra.handle, bounds.ctypes.data, q.data_ptr(), o64.data_ptr(), len(cut) - 1, out.data_ptr(), stream))
+
+	def launch_flat():
+		_shim.check(lib.ogd_tri_eval_dev(
+			inner.handle, extra.handle, bounds.ctypes.data, q.data_ptr(), len(q), out.data_ptr(), stream))
+
+	for what, launch in (("wavefront per ring", launch_rings), ("wavefront per <= 64-vertex piece", launch_pieces), ("flat, lane per point", launch_flat)):
+		for _ in range(3):
+			launch()
+		torch.cuda.synchronize()
+		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		e0.record()
+		for _ in range(20):
+			launch()
+		e1.record()
+		torch.cuda.synchronize()
+		ms = e0.elapsed_time(e1) / 20
+		n = len(q)
+		print("K3 %s, %s: %d rings (longest %d), %d points: %.1f us  %.2f Gpoints/s  (%.1f GB/s of 32 B/point)" % (
+			"heavy" if heavy else "normal", what, n_rings, int(np.diff(off).max()), n, ms * 1e3, n / ms / 1e6, n * 32 / ms / 1e6))
