@@ -54,7 +54,8 @@ def build_library(force=False, verbose=False):
 	procs = []
 	for src in SOURCES:
 		obj = obj_dir / (Path(src).stem + ".o")
-		cmd = [hipcc()] + HIPCC_FLAGS + ["-c", str(CSRC / src), "-o", str(obj)]
+		# OGD_EXTRA_FLAGS: extra -D switches for kernel experiments (tools/); the shipped library is built without
+		cmd = [hipcc()] + HIPCC_FLAGS + os.environ.get("OGD_EXTRA_FLAGS", "").split() + ["-c", str(CSRC / src), "-o", str(obj)]
 		if verbose:
 			print(" ".join(cmd), file=sys.stderr)
 		procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

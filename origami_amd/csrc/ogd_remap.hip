@@ -32,15 +32,17 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
 // Launch shapes (measured, tools/kbench): K2 proper streams the map, and 64 x 8 tiles keep its row
 // segments long (512 B per wavefront and row); the fused kernel streams nothing, and a square 32 x 32 tile
 // has the smaller source window per pixel and fewer x taps / lerped node rows to build per pixel.
-template <class MapSrc> struct TileShape { static constexpr int LX = 16, RPT = 2; };
-template <> struct TileShape<MapNodes> { static constexpr int LX = 8, RPT = 4; };
+// LDSW_MC: LDS bytes per wavefront for 3 / 4 channels (6 KB: six wavefronts per SIMD; the 32 x 32 tile of the
+// fused kernel needs 8 KB for its ~40-row window).
+template <class MapSrc> struct TileShape { static constexpr int LX = 16, RPT = 2, LDSW_MC = 6144; };
+template <> struct TileShape<MapNodes> { static constexpr int LX = 8, RPT = 4, LDSW_MC = 8192; };
 
 template <int C, class MapSrc>
 static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
                          const MapSrc& ms, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
   constexpr int LX = TileShape<MapSrc>::LX, RPT = TileShape<MapSrc>::RPT;
   constexpr int TW = 4 * LX, TH = (64 / LX) * RPT;
-  constexpr int LDSW = C == 1 ? 4096 : 8192;  // source window budget per wavefront
+  constexpr int LDSW = C == 1 ? 4096 : TileShape<MapSrc>::LDSW_MC;  // source window budget per wavefront
   const int nbx = (Wd + TW - 1) / TW, nby = (Hd + TH - 1) / TH, nb = nbx * nby;
   const dim3 grid((nb + 3) / 4), block(256);
   if (interp == OGD_INTER_LINEAR)

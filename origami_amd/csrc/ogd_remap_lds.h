@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
   constexpr int TW = 4 * LX;    // tile width
   constexpr int PF = ((TW * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
   constexpr int MAXROWS = LDSW / PF;
-  constexpr int WIN_DW = ((PF / 4) * MAXROWS + 2 + 3) & ~3;  // 16-byte multiples: b128 LDS accesses in MapNodes
+  // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
+  constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
 
   __shared__ __attribute__((aligned(16))) uint32_t win_all[4 * WIN_DW];
 
@@ -367,11 +368,29 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
           const uint32_t b2 = __builtin_amdgcn_alignbyte(win[i + PF / 4 + 1], win[i + PF / 4], (uint32_t)off);
           top[0] = __builtin_amdgcn_udot4(t2, wa[r][k], 0u, false);
           bot[0] = __builtin_amdgcn_udot4(b2, wa[r][k], 0u, false);
+        } else if (C == 3) {
+          // the six bytes of the two taps of a row as aligned dwords + v_alignbyte: lo = (r0 g0 b0 r1),
+          // hi = (g1 b1 . .); v_perm pairs channel c of both taps for the dot product
+          const int i = off >> 2;
+          const uint32_t tl = __builtin_amdgcn_alignbyte(win[i + 1], win[i], (uint32_t)off);
+          const uint32_t th = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], (uint32_t)off);
+          const uint32_t bl = __builtin_amdgcn_alignbyte(win[i + PF / 4 + 1], win[i + PF / 4], (uint32_t)off);
+          const uint32_t bh = __builtin_amdgcn_alignbyte(win[i + PF / 4 + 2], win[i + PF / 4 + 1], (uint32_t)off);
+          top[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(th, tl, 0x0c0c0300u), wa[r][k], 0u, false);
+          top[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(th, tl, 0x0c0c0401u), wa[r][k], 0u, false);
+          top[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(th, tl, 0x0c0c0502u), wa[r][k], 0u, false);
+          bot[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bh, bl, 0x0c0c0300u), wa[r][k], 0u, false);
+          bot[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bh, bl, 0x0c0c0401u), wa[r][k], 0u, false);
+          bot[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(bh, bl, 0x0c0c0502u), wa[r][k], 0u, false);
         } else {
+          // four channels: a pixel is one aligned dword, the two taps of a row are neighbours
+          const int i = off >> 2;
+          const uint32_t t0 = win[i], t1 = win[i + 1], b0 = win[i + PF / 4], b1 = win[i + PF / 4 + 1];
 #pragma unroll
-          for (int c = 0; c < C; ++c) {
-            top[c] = __builtin_amdgcn_udot4((uint32_t)p[c] | ((uint32_t)p[C + c] << 8), wa[r][k], 0u, false);
-            bot[c] = __builtin_amdgcn_udot4((uint32_t)p[PF + c] | ((uint32_t)p[PF + C + c] << 8), wa[r][k], 0u, false);
+          for (int c = 0; c < 4; ++c) {
+            const uint32_t sel = 0x0c0c0400u + 0x0101u * c;  // (channel c of tap 0, channel c of tap 1)
+            top[c] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(t1, t0, sel), wa[r][k], 0u, false);
+            bot[c] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b1, b0, sel), wa[r][k], 0u, false);
           }
         }
 #pragma unroll
