@@ -141,3 +141,59 @@ def test_export_lines_stage_matches_oracle(gpu, tmp_path):
 				full = oblock.warped_grid(ogrid, p, right, up, ysteps=48).shape[1]
 				assert abs(sum(widths) - full) <= 3 and abs(widths[1] - 0.4 * full) <= 2
 		assert bad <= 1e-3 * total
+
+
+def _zip_members(path):
+	with zipfile.ZipFile(path) as zf:
+		return {n: zf.read(n) for n in zf.namelist()}
+
+
+def test_two_spawned_workers_on_one_gpu_equal_the_in_process_run(gpu, tmp_path):
+	"""`--gpus 2` on a one-GPU box: both spawned workers bind GPU 0 (devices[r % 1]), create their own HIP
+	context after the spawn and share the page queue; every artifact equals the in-process run byte for byte
+	(ref: origami/batch/core/processor.py:470-515, one process per GPU instead of the forked Pool)."""
+	import shutil
+	rng = np.random.default_rng(21)
+	a = tmp_path / "a"
+	a.mkdir()
+	for k in range(4):
+		synth.write_page_dir(
+			a, "page%04d" % k, rng, size=(500, 650), n_h=100, n_v=130, n_regions=10, n_separators=2,
+			label_size=(250, 325))
+	b = tmp_path / "b"
+	shutil.copytree(a, b)
+	res = CliRunner().invoke(dewarp, [str(a), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	res = CliRunner().invoke(dewarp, [str(b), "--gpus", "2", "--plain"])
+	assert res.exit_code == 0, res.output
+	for k in range(4):
+		oa, ob = a / ("page%04d.out" % k), b / ("page%04d.out" % k)
+		assert json.loads((ob / "runtime.json").read_text())["origami.batch.detect.dewarp"]["status"] == "COMPLETED"
+		for name in ("dewarp.zip", "contours.1.zip"):
+			assert _zip_members(oa / name) == _zip_members(ob / name), (k, name)
+
+
+def test_entry_points_are_thread_safe(gpu):
+	"""Callers are thread pools (ref: origami/core/dewarp.py:481-483, origami/batch/core/lines.py:148): eight
+	threads dewarp different pages and query the transformer at once; results equal the serial ones."""
+	from multiprocessing.pool import ThreadPool
+	rng = np.random.default_rng(22)
+	size = (700, 900)
+	jobs = []
+	for k in range(8):
+		nodes = synth.Warp(size, 0.02 + 0.002 * k, 0.02, 1, 2).node_grid(25)
+		jobs.append((synth.text_page(rng, size), nodes, rng.uniform([0, 0], size, size=(500, 2))))
+	grids = [Grid(nodes, 25) for _, nodes, _ in jobs]
+
+	def work(i):
+		page, nodes, q = jobs[i]
+		x, y = grids[i].transformer(tuple(q[:, 0]), tuple(q[:, 1]))
+		return gpu.dewarp_u8(page, nodes, 25), np.stack([x, y], axis=1)
+
+	serial = [work(i) for i in range(8)]
+	with ThreadPool(8) as pool:
+		for _ in range(3):
+			threaded = pool.map(work, range(8))
+			for (p0, t0), (p1, t1) in zip(serial, threaded):
+				np.testing.assert_array_equal(p0, p1)
+				np.testing.assert_array_equal(t0, t1)
