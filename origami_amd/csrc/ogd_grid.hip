@@ -3,16 +3,19 @@
 //
 // HBM-bound: 8 B written per dense pixel, 8 B read per node (nodes stay in L1/L2: 628 KB at
 // 323 x 243).  Each thread owns two adjacent columns and walks GF_ROWS rows, so the horizontal
-// taps are computed once per thread and the horizontally-lerped node rows are re-used for all dense
-// rows that fall into the same node cell; every store is a 16-byte float4 and a wavefront writes
+// taps are computed once per thread and the horizontally-lerped node rows are re-used for the dense
+// rows of the walk that fall into the same node cell; every store is a 16-byte float4 and a wavefront writes
 // 1 KiB of one dense row per instruction.
 #include "ogd_common.h"
 #include "ogd_resize_math.h"
 
 namespace ogd {
 
-constexpr int GF_THREADS = 256;
-constexpr int GF_ROWS = 16;
+// 512 threads x 2 columns and 4 rows per workgroup: measured (tools/kbench "K1a") against 8 .. 64 rows and 256 ..
+// 1024 threads — fewer rows per thread stream faster (91 vs 103 us alone, 178 vs 195 us with the K2 that follows),
+// two rows or plain stores are faster alone but slow that K2 down by more than they gain.
+constexpr int GF_THREADS = 512;
+constexpr int GF_ROWS = 4;
 
 typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 

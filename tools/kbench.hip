@@ -167,6 +167,48 @@ __global__ __launch_bounds__(256) void map_stream_tile(const float* __restrict__
     }
 }
 
+// K1a lab: store policy, rows per thread and block width of the grid fill (copy of grid_fill_kernel's loop)
+#include "../origami_amd/csrc/ogd_resize_math.h"
+template <int NT, int ROWS, int THREADS>
+__global__ __launch_bounds__(THREADS) void grid_fill_variant(const float2* __restrict__ nodes, int h, int w,
+                                                             double inv_s, float2* __restrict__ out, int Hd, int Wd) {
+  const int X = (blockIdx.x * THREADS + threadIdx.x) * 2;
+  if (X >= Wd) return;
+  const bool pair = (X + 1 < Wd);
+  const Tap tx0 = tap_x(X, inv_s, w);
+  const Tap tx1 = tap_x(pair ? X + 1 : X, inv_s, w);
+  const int Y0 = blockIdx.y * ROWS, Y1 = min(Y0 + ROWS, Hd);
+  int cur0 = -1, cur1 = -1;
+  float2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f}, tb0 = {0.f, 0.f}, tb1 = {0.f, 0.f};
+  for (int Y = Y0; Y < Y1; ++Y) {
+    const Tap ty = tap_y(Y, inv_s, h);
+    if (ty.i0 != cur0 || ty.i1 != cur1) {
+      const float2* r0 = nodes + (size_t)ty.i0 * w;
+      const float2* r1 = nodes + (size_t)ty.i1 * w;
+      float2 a = r0[tx0.i0], b = r0[tx0.i1], c = r0[tx1.i0], d = r0[tx1.i1];
+      ta0 = make_float2(lerp2(a.x, tx0.w0, b.x, tx0.w1), lerp2(a.y, tx0.w0, b.y, tx0.w1));
+      ta1 = make_float2(lerp2(c.x, tx1.w0, d.x, tx1.w1), lerp2(c.y, tx1.w0, d.y, tx1.w1));
+      a = r1[tx0.i0], b = r1[tx0.i1], c = r1[tx1.i0], d = r1[tx1.i1];
+      tb0 = make_float2(lerp2(a.x, tx0.w0, b.x, tx0.w1), lerp2(a.y, tx0.w0, b.y, tx0.w1));
+      tb1 = make_float2(lerp2(c.x, tx1.w0, d.x, tx1.w1), lerp2(c.y, tx1.w0, d.y, tx1.w1));
+      cur0 = ty.i0;
+      cur1 = ty.i1;
+    }
+    f4a8 v;
+    v.x = lerp2(ta0.x, ty.w0, tb0.x, ty.w1);
+    v.y = lerp2(ta0.y, ty.w0, tb0.y, ty.w1);
+    v.z = lerp2(ta1.x, ty.w0, tb1.x, ty.w1);
+    v.w = lerp2(ta1.y, ty.w0, tb1.y, ty.w1);
+    float2* o = out + (size_t)Y * Wd + X;
+    if (!pair)
+      *o = make_float2(v.x, v.y);
+    else if (NT == 1)
+      __builtin_nontemporal_store(v, reinterpret_cast<f4a8*>(o));
+    else
+      *reinterpret_cast<f4a8*>(o) = v;
+  }
+}
+
 struct Ctx {
   int W, H, Wd, Hd, iters;
   uint8_t *src, *dst, *ref;
@@ -271,6 +313,32 @@ int main(int argc, char** argv) {
   }
   OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr));
   CK(hipDeviceSynchronize());
+
+  // K1a lab: alone (check = false: the map is the output) and followed by the library's K2
+#define K1A_VARIANT(NT, ROWS, THREADS)                                                                    \
+  {                                                                                                       \
+    auto k1a = [&] {                                                                                      \
+      hipLaunchKernelGGL((grid_fill_variant<NT, ROWS, THREADS>),                                          \
+                         dim3((c.Wd + 2 * THREADS - 1) / (2 * THREADS), (c.Hd + ROWS - 1) / ROWS),        \
+                         dim3(THREADS), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, (float2*)c.map,   \
+                         c.Hd, c.Wd);                                                                     \
+    };                                                                                                    \
+    run(c, "K1a alone nt=" #NT " rows=" #ROWS " threads=" #THREADS, k1a, false);                          \
+    run(c, "K1a+K2    nt=" #NT " rows=" #ROWS " threads=" #THREADS, [&] { k1a(); lib(); });               \
+  }
+  K1A_VARIANT(1, 16, 256)
+  K1A_VARIANT(0, 16, 256)
+  K1A_VARIANT(1, 8, 256)
+  K1A_VARIANT(1, 4, 256)
+  K1A_VARIANT(1, 8, 512)
+  K1A_VARIANT(1, 4, 512)
+  K1A_VARIANT(1, 8, 1024)
+  K1A_VARIANT(1, 4, 1024)
+  K1A_VARIANT(1, 2, 1024)
+  K1A_VARIANT(1, 1, 1024)
+  K1A_VARIANT(0, 4, 1024)
+  run(c, "library K1a alone", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); }, false);
+  run(c, "library K1a + K2", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); lib(); });
 
   const int nbx = (c.Wd + 255) / 256;
 #define ROWS_VARIANT(R, NT, XCD)                                                                        \
