@@ -59,57 +59,81 @@ __global__ __launch_bounds__(256) void tri_eval_ragged_kernel(TriView inner, int
   }
 }
 
-// K1b — barycentric rasteriser on a lattice.  One block per RS_TW x RS_TH lattice tile.  The tile's
-// (clipped) extent selects a rectangle of bucket cells; for every such cell the block stages the
-// triangle records of the cell in LDS (chunks of RS_CHUNK), and the lattice points that fall into
-// that cell test the staged triangles in list order — the same order tri_locate uses, so the
-// rasteriser is bit-identical to point queries.  Points the inner triangulation leaves open take
-// a second pass over the extrapolation triangulation.
-constexpr int RS_TW = 32, RS_TH = 8, RS_CHUNK = 96;
+// K1b — barycentric rasteriser on a lattice.  One workgroup per RS_TW x RS_TH lattice tile, RS_PX lattice
+// rows per thread.  The tile's (clipped) extent selects a rectangle of bucket cells.  The bucket grid is a
+// row-major CSR, so the triangle lists of one cell ROW of that rectangle are one contiguous range of
+// cell_tris: the workgroup stages the records of that range in LDS (chunks of RS_CAP records, three
+// dependent memory round trips per chunk for 2048 lattice points), and every lattice point tests the
+// staged records of its own cell in list order — the order tri_locate uses, so the rasteriser is
+// bit-identical to point queries.  Points the inner triangulation leaves open take a second pass over
+// the extrapolation triangulation.
+constexpr int RS_TW = 64, RS_TH = 16, RS_THREADS = 256, RS_PX = RS_TH / (RS_THREADS / RS_TW), RS_CAP = 160;
 
 template <int NV>
-__device__ __forceinline__ void raster_pass(const TriView& t, double* lds, double x, double y,
-                                            bool& found, double* val, double tx0, double ty0,
-                                            double tx1, double ty1) {
+__device__ __forceinline__ void raster_pass(const TriView& t, double* lds, double x, const double (&y)[RS_PX],
+                                            bool (&found)[RS_PX], double (&val)[RS_PX][NV], double tx0,
+                                            double ty0, double tx1, double ty1) {
   constexpr int REC = 6 + 3 * NV;
-  const int tid = threadIdx.y * RS_TW + threadIdx.x;
-  const int own = cell_of(t, x, y);
-  // cell rectangle touched by this tile (block-uniform: derived from the tile corners)
+  const int tid = threadIdx.x;
+  // cell rectangle touched by this tile (workgroup-uniform: derived from the tile corners; cell_of is monotone)
   const int c00 = cell_of(t, tx0, ty0), c11 = cell_of(t, tx1, ty1);
   const int cx0 = c00 % t.gnx, cy0 = c00 / t.gnx, cx1 = c11 % t.gnx, cy1 = c11 / t.gnx;
+  int own[RS_PX];
+#pragma unroll
+  for (int j = 0; j < RS_PX; ++j) own[j] = cell_of(t, x, y[j]);
   for (int cy = cy0; cy <= cy1; ++cy) {
-    for (int cx = cx0; cx <= cx1; ++cx) {
-      const int c = cy * t.gnx + cx;
-      const int b = t.cell_start[c], e = t.cell_start[c + 1];
-      for (int base = b; base < e; base += RS_CHUNK) {
-        const int n = min(RS_CHUNK, e - base);
-        __syncthreads();  // previous chunk fully consumed
-        for (int idx = tid; idx < n * REC; idx += RS_TW * RS_TH) {
-          const int k = idx / REC, f = idx - k * REC;
-          lds[idx] = t.rec[(size_t)t.cell_tris[base + k] * REC + f];
-        }
-        __syncthreads();
-        if (!found && own == c) {
-          for (int k = 0; k < n; ++k)
-            if (tri_try<NV>(lds + k * REC, x, y, val)) {
-              found = true;
-              break;
-            }
-        }
+    const int b = t.cell_start[cy * t.gnx + cx0], e = t.cell_start[cy * t.gnx + cx1 + 1];
+    // list range of every point of this thread that lies in cell row cy and is still open
+    int ob[RS_PX], oe[RS_PX];
+#pragma unroll
+    for (int j = 0; j < RS_PX; ++j) {
+      const bool here = !found[j] && own[j] / t.gnx == cy;
+      ob[j] = here ? t.cell_start[own[j]] : 0;
+      oe[j] = here ? t.cell_start[own[j] + 1] : 0;
+    }
+    for (int base = b; base < e; base += RS_CAP) {
+      const int n = min(RS_CAP, e - base);
+      __syncthreads();  // previous chunk fully consumed
+      for (int idx = tid; idx < n * REC; idx += RS_THREADS) {
+        const int k = idx / REC, f = idx - k * REC;
+        lds[idx] = t.rec[(size_t)t.cell_tris[base + k] * REC + f];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RS_PX; ++j) {
+        const int k0 = max(ob[j], base) - base, k1 = min(oe[j], base + n) - base;
+        for (int k = k0; k < k1; ++k)
+          if (tri_try<NV>(lds + k * REC, x, y[j], val[j])) {
+            found[j] = true;
+            oe[j] = 0;  // closed
+            break;
+          }
       }
     }
   }
 }
 
 template <int NV, typename OutT>
-__global__ __launch_bounds__(RS_TW* RS_TH) void tri_rasterize_kernel(
+__global__ __launch_bounds__(RS_THREADS) void tri_rasterize_kernel(
     TriView inner, int has_inner, TriView extra, Bounds b, double x0, double y0, double step, int nx,
     int ny, OutT* __restrict__ out, int64_t stride_x, int64_t stride_y) {
-  __shared__ double lds[RS_CHUNK * (6 + 3 * NV)];
-  const int ix = blockIdx.x * RS_TW + threadIdx.x, iy = blockIdx.y * RS_TH + threadIdx.y;
-  const bool live = ix < nx && iy < ny;
+  __shared__ double lds[RS_CAP * (6 + 3 * NV)];
+  const int lx = threadIdx.x % RS_TW, ly = threadIdx.x / RS_TW;
+  const int ix = blockIdx.x * RS_TW + lx, iy0 = blockIdx.y * RS_TH + ly;  // rows iy0 + j * (RS_TH / RS_PX)
+  constexpr int RSTEP = RS_THREADS / RS_TW;
   // lattice coordinates: x0 + i*step is exact for the integer lattices the reference uses
-  double x = x0 + (double)min(ix, nx - 1) * step, y = y0 + (double)min(iy, ny - 1) * step;
+  double x = x0 + (double)min(ix, nx - 1) * step;
+  double y[RS_PX];
+  bool found[RS_PX];
+  double val[RS_PX][NV];
+#pragma unroll
+  for (int j = 0; j < RS_PX; ++j) {
+    const int iy = iy0 + j * RSTEP;
+    y[j] = y0 + (double)min(iy, ny - 1) * step;
+    found[j] = !(ix < nx && iy < ny);  // points beyond the lattice take no part
+#pragma unroll
+    for (int k = 0; k < NV; ++k) val[j][k] = __longlong_as_double(0x7ff8000000000000LL);
+  }
   const int ixl = min((int)(blockIdx.x * RS_TW + RS_TW - 1), nx - 1);
   const int iyl = min((int)(blockIdx.y * RS_TH + RS_TH - 1), ny - 1);
   double tx0 = x0 + (double)(blockIdx.x * RS_TW) * step, ty0 = y0 + (double)(blockIdx.y * RS_TH) * step;
@@ -120,22 +144,28 @@ __global__ __launch_bounds__(RS_TW* RS_TH) void tri_rasterize_kernel(
   }
   if (b.clip) {
     x = clipd(x, b.minx, b.maxx);
-    y = clipd(y, b.miny, b.maxy);
+#pragma unroll
+    for (int j = 0; j < RS_PX; ++j) y[j] = clipd(y[j], b.miny, b.maxy);
     tx0 = clipd(tx0, b.minx, b.maxx);
     tx1 = clipd(tx1, b.minx, b.maxx);
     ty0 = clipd(ty0, b.miny, b.maxy);
     ty1 = clipd(ty1, b.miny, b.maxy);
   }
-  bool found = !live;
-  double val[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) val[k] = __longlong_as_double(0x7ff8000000000000LL);
   if (has_inner) raster_pass<NV>(inner, lds, x, y, found, val, tx0, ty0, tx1, ty1);
-  if (__syncthreads_or(!found)) raster_pass<NV>(extra, lds, x, y, found, val, tx0, ty0, tx1, ty1);
-  if (live) {
-    OutT* o = out + (int64_t)ix * stride_x + (int64_t)iy * stride_y;
+  bool open = false;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) o[k] = (OutT)val[k];
+  for (int j = 0; j < RS_PX; ++j) open = open || !found[j];
+  if (__syncthreads_or(open)) raster_pass<NV>(extra, lds, x, y, found, val, tx0, ty0, tx1, ty1);
+  if (ix < nx) {
+#pragma unroll
+    for (int j = 0; j < RS_PX; ++j) {
+      const int iy = iy0 + j * RSTEP;
+      if (iy < ny) {
+        OutT* o = out + (int64_t)ix * stride_x + (int64_t)iy * stride_y;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) o[k] = (OutT)val[j][k];
+      }
+    }
   }
 }
 
@@ -280,7 +310,9 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
 
   // bucket grid: about one cell per triangle, aspect-matched, at most 2048 per side
   const double ex = std::max(bx1 - bx0, 1e-300), ey = std::max(by1 - by0, 1e-300);
-  double fx = std::sqrt((double)nt * ex / ey), fy = std::sqrt((double)nt * ey / ex);
+  double density = 1.0;
+  if (const char* dv = std::getenv("OGD_BUCKET_DENSITY")) density = std::max(0.25, std::atof(dv));  // experiments
+  double fx = std::sqrt(density * (double)nt * ex / ey), fy = std::sqrt(density * (double)nt * ey / ex);
   const int gnx = (int)std::min(2048.0, std::max(1.0, std::floor(fx)));
   const int gny = (int)std::min(2048.0, std::max(1.0, std::floor(fy)));
   const double cw = ex / gnx, ch = ey / gny;
@@ -471,7 +503,7 @@ int ogd_tri_rasterize_dev(const ogd_tri* inner, const ogd_tri* extra, const doub
   OGD_REQUIRE(std::isfinite(x0) && std::isfinite(y0) && std::isfinite(step), "lattice is not finite");
   OGD_REQUIRE(d_out != nullptr, "null pointer");
   OGD_TRY(ensure_device());
-  dim3 block(RS_TW, RS_TH), grid((nx + RS_TW - 1) / RS_TW, (ny + RS_TH - 1) / RS_TH);
+  dim3 block(RS_THREADS), grid((nx + RS_TW - 1) / RS_TW, (ny + RS_TH - 1) / RS_TH);
   OGD_REQUIRE(grid.y <= 65535u, "lattice too tall");
   const TriView ve = view_of(extra), vi = inner ? view_of(inner) : ve;
   const Bounds b = make_bounds(bounds);
