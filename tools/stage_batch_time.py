@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput (iii) of SURVEY §8d: the `dewarp` batch stage end to end (directory walk, artifact I/O,
 grid construction, contour warp, zip output) on synthetic broadsheet page directories, one worker on one GPU.
-usage: stage_batch_time.py [n_pages n_polygons [W H]]   (never bench.py's `value`)"""
+usage: stage_batch_time.py [n_pages n_polygons [W H [workers]]]   (workers > 0: spawned workers, all on GPU 0 of a one-GPU box)   (never bench.py's `value`)"""
 import cProfile
 import pstats
 import shutil
@@ -17,40 +17,49 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from origami_amd import _shim, synth  # noqa: E402
 from origami_amd.batch.detect.dewarp import dewarp  # noqa: E402
 
-n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-n_poly = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6000, 8000)
+def main():
+	n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+	n_poly = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+	W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6000, 8000)
+	workers = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 
-_shim.init(0)
-root = Path(tempfile.mkdtemp(prefix="ogd_stage_"))
-try:
-	rng = np.random.default_rng(1)
-	t0 = time.perf_counter()
-	first = synth.write_page_dir(root, "page0000", rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
-	for k in range(1, n_pages):  # same pixels (the stage reads only the size), own warp / flow / contours
-		page = root / ("page%04d.png" % k)
-		shutil.copyfile(first, page)
-		synth.write_page_inputs(page, rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
-	print("wrote %d page directories %dx%d, %d polygons each, in %.1f s" % (n_pages, W, H, n_poly, time.perf_counter() - t0))
+	_shim.init(0)
+	root = Path(tempfile.mkdtemp(prefix="ogd_stage_"))
+	try:
+		rng = np.random.default_rng(1)
+		t0 = time.perf_counter()
+		first = synth.write_page_dir(root, "page0000", rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
+		for k in range(1, n_pages):  # same pixels (the stage reads only the size), own warp / flow / contours
+			page = root / ("page%04d.png" % k)
+			shutil.copyfile(first, page)
+			synth.write_page_inputs(page, rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
+		print("wrote %d page directories %dx%d, %d polygons each, in %.1f s" % (n_pages, W, H, n_poly, time.perf_counter() - t0))
 
-	def run(overwrite):
-		args = [str(root), "--lock-strategy", "NONE", "--plain"] + (["--overwrite"] if overwrite else [])
-		t = time.perf_counter()
-		res = CliRunner().invoke(dewarp, args)
-		assert res.exit_code == 0, res.output
-		return time.perf_counter() - t
+		def run(overwrite):
+			args = [str(root), "--lock-strategy", "NONE", "--plain"] + (["--overwrite"] if overwrite else [])
+			if workers:
+				args += ["--gpus", str(workers)]
+			t = time.perf_counter()
+			res = CliRunner().invoke(dewarp, args)
+			assert res.exit_code == 0, res.output
+			return time.perf_counter() - t
 
-	dt = run(False)
-	print("first pass : %.3f s = %.1f ms/page (includes context creation and first-use costs)" % (dt, 1e3 * dt / n_pages))
-	dt = run(True)
-	mp = n_pages * W * H / 1e6
-	print("second pass: %.3f s = %.1f ms/page = %.0f MP/s (page megapixels per second through the stage)" % (
-		dt, 1e3 * dt / n_pages, mp / dt))
-	pr = cProfile.Profile()
-	pr.enable()
-	run(True)
-	pr.disable()
-	pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
-	pstats.Stats(pr).sort_stats("tottime").print_stats(22)
-finally:
-	shutil.rmtree(root, ignore_errors=True)
+		dt = run(False)
+		print("first pass : %.3f s = %.1f ms/page (includes context creation and first-use costs)" % (dt, 1e3 * dt / n_pages))
+		dt = run(True)
+		mp = n_pages * W * H / 1e6
+		print("second pass: %.3f s = %.1f ms/page = %.0f MP/s (page megapixels per second through the stage)" % (
+			dt, 1e3 * dt / n_pages, mp / dt))
+		if not workers:
+			pr = cProfile.Profile()
+			pr.enable()
+			run(True)
+			pr.disable()
+			pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+			pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+	finally:
+		shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":  # spawned workers import this module: nothing may run at import time
+	main()
