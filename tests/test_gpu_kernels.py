@@ -266,3 +266,51 @@ def test_rings_self_cross_matches_host_geometry(gpu):
 	np.testing.assert_array_equal(got, want)
 	assert want[:300].sum() == 0 and want[300:400].sum() > 50
 	assert len(gpu.rings_self_cross([])) == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 32767), (32767, 3)])
+def test_remap_at_the_int16_coordinate_limit(gpu, shape):
+	"""Largest image remap accepts (H, W < 32768: cv2.remap's int16 coordinates): taps at and beyond the far
+	edge, where the packed int16 bounding box of a tile runs up to 32767 and the zero border starts."""
+	H, W = shape
+	rng = np.random.default_rng(H)
+	src = rng.integers(1, 256, size=(H, W), dtype=np.uint8)
+	n = 4096
+	far = np.array([W, H], dtype=np.float32)
+	m = np.empty((8, n, 2), dtype=np.float32)
+	m[..., 0] = rng.uniform(W - 70, W + 3, size=(8, n))
+	m[..., 1] = rng.uniform(H - 70, H + 3, size=(8, n))
+	m[0, :8] = far - np.array([[1, 1], [0.5, 1], [1, 0.5], [1.015625, 1.015625], [0, 0], [2, 2], [1, 40000], [40000, 1]], dtype=np.float32)
+	m = np.maximum(m, -5)
+	for interp in (ocv.INTER_LINEAR, ocv.INTER_NEAREST):
+		np.testing.assert_array_equal(gpu.remap_u8(src, m, interp), ocv.remap_u8(src, m, interp))
+	# smooth map along the long axis: the LDS window path, not only the erratic-map fallback
+	k = max(H, W)
+	t = np.arange(k - 4000, k + 40, dtype=np.float32)
+	sm = np.zeros((8, len(t), 2), dtype=np.float32)
+	if W > H:
+		sm[..., 0] = t[None, :] + 0.3
+		sm[..., 1] = np.linspace(-0.5, 2.5, 8, dtype=np.float32)[:, None]
+	else:
+		sm[..., 1] = t[None, :] + 0.3
+		sm[..., 0] = np.linspace(-0.5, 2.5, 8, dtype=np.float32)[:, None]
+	np.testing.assert_array_equal(gpu.remap_u8(src, sm), ocv.remap_u8(src, sm))
+	with pytest.raises(gpu.OgdError):
+		gpu.remap_u8(np.zeros((2, 32768), dtype=np.uint8), m)
+
+
+def test_empty_and_degenerate_inputs(gpu):
+	"""Empty ragged batches, rings of one point, a 1 x 1 node grid, a 1 x 1 map."""
+	pts = np.array([[0, 0], [10, 0], [0, 10], [10, 10]], dtype=np.float64)
+	vals = np.array([[0.0, 1.0], [1.0, 1.0], [0.0, 2.0], [1.0, 2.0]])
+	tri = gpu.Triangulation(pts, np.array([[0, 1, 2], [1, 3, 2]], dtype=np.int32), vals)
+	assert gpu.tri_eval(None, tri, None, np.empty((0, 2))).shape == (0, 2)
+	assert gpu.tri_eval_ragged(None, tri, None, np.empty((0, 2)), np.zeros(1, dtype=np.int64)).shape == (0, 2)
+	out = gpu.tri_eval_ragged(None, tri, None, np.array([[5.0, 5.0], [1.0, 1.0]]), np.array([0, 0, 1, 1, 2], dtype=np.int64))
+	np.testing.assert_allclose(out, [[0.5, 1.5], [0.1, 1.1]], atol=1e-12)
+	assert np.isnan(gpu.tri_eval(None, tri, None, np.array([[20.0, 20.0]]))).all()  # outside: NaN, like scipy
+	one = np.array([[[3.25, 7.5]]], dtype=np.float32)
+	np.testing.assert_array_equal(gpu.grid_fill(one, 4), np.broadcast_to(one, (4, 4, 2)))
+	src = np.arange(12, dtype=np.uint8).reshape(3, 4)
+	np.testing.assert_array_equal(gpu.remap_u8(src, np.array([[[2.0, 1.0]]], dtype=np.float32)), [[6]])
+	np.testing.assert_array_equal(gpu.dewarp_u8(src, np.array([[[2.0, 1.0]]], dtype=np.float32), 2), np.full((2, 2), 6, dtype=np.uint8))
