@@ -63,35 +63,95 @@ __global__ __launch_bounds__(256) void tri_eval_ragged_kernel(TriView inner, int
 // K1b — barycentric rasteriser on a lattice.  One workgroup per RS_TW x RS_TH lattice tile, RS_PX lattice
 // rows per thread.  The tile's (clipped) extent selects a rectangle of bucket cells.  The bucket grid is a
 // row-major CSR, so the triangle lists of one cell ROW of that rectangle are one contiguous range of
-// cell_tris: the workgroup stages the records of that range in LDS (chunks of RS_CAP records, three
-// dependent memory round trips per chunk for 2048 lattice points), and every lattice point tests the
-// staged records of its own cell in list order — the order tri_locate uses, so the rasteriser is
+// cell_tris: the workgroup stages the records of those ranges in LDS — all cell rows of the tile at once when
+// they fit (three dependent memory round trips per tile), else row by row in chunks of RS_CAP records — and
+// every lattice point tests the staged records of its own cell in list order — the order tri_locate uses, so the rasteriser is
 // bit-identical to point queries.  Points the inner triangulation leaves open take a second pass over
 // the extrapolation triangulation.
 constexpr int RS_TW = 64, RS_TH = 16, RS_THREADS = 256, RS_PX = RS_TH / (RS_THREADS / RS_TW), RS_CAP = 160;
 
+__device__ __forceinline__ void cell_xy(const TriView& t, double x, double y, int& cx, int& cy) {
+  cx = min(max((int)floor((x - t.gx0) * t.inv_cw), 0), t.gnx - 1);  // as cell_of, without the division to split it
+  cy = min(max((int)floor((y - t.gy0) * t.inv_ch), 0), t.gny - 1);
+}
+
+constexpr int RS_MAXROWS = 8;                                // cell rows staged in one go
+constexpr int RS_META = 3 * RS_MAXROWS + 1 + RS_CAP;         // ints: row begin | row length | prefix | triangle ids
+
+// One pass of a tile over one triangulation.  Fast path (the tile's cell rectangle has <= RS_MAXROWS rows and
+// <= RS_CAP list entries, i.e. practically always): the list ranges of ALL its cell rows are staged at once —
+// three dependent memory round trips per tile (row ranges, triangle ids, records) instead of three per cell
+// row.  Otherwise cell row by cell row, in chunks.  Either way every lattice point tests the records of its
+// own cell in list order.
 template <int NV>
-__device__ __forceinline__ void raster_pass(const TriView& t, double* lds, double x, const double (&y)[RS_PX],
-                                            bool (&found)[RS_PX], double (&val)[RS_PX][NV], double tx0,
-                                            double ty0, double tx1, double ty1) {
+__device__ __forceinline__ void raster_pass(const TriView& t, double* lds, int* meta, double x,
+                                            const double (&y)[RS_PX], bool (&found)[RS_PX],
+                                            double (&val)[RS_PX][NV], double tx0, double ty0, double tx1,
+                                            double ty1) {
   constexpr int REC = 6 + 3 * NV;
   const int tid = threadIdx.x;
-  // cell rectangle touched by this tile (workgroup-uniform: derived from the tile corners; cell_of is monotone)
-  const int c00 = cell_of(t, tx0, ty0), c11 = cell_of(t, tx1, ty1);
-  const int cx0 = c00 % t.gnx, cy0 = c00 / t.gnx, cx1 = c11 % t.gnx, cy1 = c11 / t.gnx;
-  int own[RS_PX];
+  int* rb = meta;
+  int* rlen = meta + RS_MAXROWS;
+  int* pre = meta + 2 * RS_MAXROWS;  // RS_MAXROWS + 1 entries
+  int* ids = meta + 3 * RS_MAXROWS + 1;
+  // cell rectangle touched by this tile (workgroup-uniform: from the tile corners; the cell index is monotone)
+  int cx0, cy0, cx1, cy1;
+  cell_xy(t, tx0, ty0, cx0, cy0);
+  cell_xy(t, tx1, ty1, cx1, cy1);
+  const int nr = cy1 - cy0 + 1;
+  // every open point's own list range (loads in flight while the tile's lists are staged)
+  int ocx, ocy[RS_PX], ob[RS_PX], oe[RS_PX];
 #pragma unroll
-  for (int j = 0; j < RS_PX; ++j) own[j] = cell_of(t, x, y[j]);
-  for (int cy = cy0; cy <= cy1; ++cy) {
-    const int b = t.cell_start[cy * t.gnx + cx0], e = t.cell_start[cy * t.gnx + cx1 + 1];
-    // list range of every point of this thread that lies in cell row cy and is still open
-    int ob[RS_PX], oe[RS_PX];
+  for (int j = 0; j < RS_PX; ++j) {
+    cell_xy(t, x, y[j], ocx, ocy[j]);
+    const int c = ocy[j] * t.gnx + ocx;
+    ob[j] = found[j] ? 0 : t.cell_start[c];
+    oe[j] = found[j] ? 0 : t.cell_start[c + 1];
+  }
+  __syncthreads();  // the previous pass is done with meta / lds
+  if (tid < min(nr, RS_MAXROWS)) {
+    const int b = t.cell_start[(cy0 + tid) * t.gnx + cx0];
+    rb[tid] = b;
+    rlen[tid] = t.cell_start[(cy0 + tid) * t.gnx + cx1 + 1] - b;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < min(nr, RS_MAXROWS); ++r) {
+      pre[r] = run;
+      run += rlen[r];
+    }
+    pre[min(nr, RS_MAXROWS)] = run;
+  }
+  __syncthreads();
+  const int total = pre[min(nr, RS_MAXROWS)];
+  if (nr <= RS_MAXROWS && total <= RS_CAP) {  // workgroup-uniform
+    for (int k = tid; k < total; k += RS_THREADS) {
+      int r = 0;
+      while (k >= pre[r + 1]) ++r;
+      ids[k] = t.cell_tris[rb[r] + k - pre[r]];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < total * REC; idx += RS_THREADS) {
+      const int k = idx / REC, f = idx - k * REC;
+      lds[idx] = t.rec[(size_t)ids[k] * REC + f];
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_PX; ++j) {
-      const bool here = !found[j] && own[j] / t.gnx == cy;
-      ob[j] = here ? t.cell_start[own[j]] : 0;
-      oe[j] = here ? t.cell_start[own[j] + 1] : 0;
+      if (found[j]) continue;
+      const int r = ocy[j] - cy0;
+      const int k0 = pre[r] + (ob[j] - rb[r]), k1 = k0 + (oe[j] - ob[j]);
+      for (int k = k0; k < k1; ++k)
+        if (tri_try<NV>(lds + k * REC, x, y[j], val[j])) {
+          found[j] = true;
+          break;
+        }
     }
+    return;
+  }
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    const int b = t.cell_start[cy * t.gnx + cx0], e = t.cell_start[cy * t.gnx + cx1 + 1];
     for (int base = b; base < e; base += RS_CAP) {
       const int n = min(RS_CAP, e - base);
       __syncthreads();  // previous chunk fully consumed
@@ -102,11 +162,11 @@ __device__ __forceinline__ void raster_pass(const TriView& t, double* lds, doubl
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < RS_PX; ++j) {
+        if (found[j] || ocy[j] != cy) continue;
         const int k0 = max(ob[j], base) - base, k1 = min(oe[j], base + n) - base;
         for (int k = k0; k < k1; ++k)
           if (tri_try<NV>(lds + k * REC, x, y[j], val[j])) {
             found[j] = true;
-            oe[j] = 0;  // closed
             break;
           }
       }
@@ -119,6 +179,7 @@ __global__ __launch_bounds__(RS_THREADS) void tri_rasterize_kernel(
     TriView inner, int has_inner, TriView extra, Bounds b, double x0, double y0, double step, int nx,
     int ny, OutT* __restrict__ out, int64_t stride_x, int64_t stride_y) {
   __shared__ double lds[RS_CAP * (6 + 3 * NV)];
+  __shared__ int meta[RS_META];
   const int lx = threadIdx.x % RS_TW, ly = threadIdx.x / RS_TW;
   const int ix = blockIdx.x * RS_TW + lx, iy0 = blockIdx.y * RS_TH + ly;  // rows iy0 + j * (RS_TH / RS_PX)
   constexpr int RSTEP = RS_THREADS / RS_TW;
@@ -152,11 +213,11 @@ __global__ __launch_bounds__(RS_THREADS) void tri_rasterize_kernel(
     ty0 = clipd(ty0, b.miny, b.maxy);
     ty1 = clipd(ty1, b.miny, b.maxy);
   }
-  if (has_inner) raster_pass<NV>(inner, lds, x, y, found, val, tx0, ty0, tx1, ty1);
+  if (has_inner) raster_pass<NV>(inner, lds, meta, x, y, found, val, tx0, ty0, tx1, ty1);
   bool open = false;
 #pragma unroll
   for (int j = 0; j < RS_PX; ++j) open = open || !found[j];
-  if (__syncthreads_or(open)) raster_pass<NV>(extra, lds, x, y, found, val, tx0, ty0, tx1, ty1);
+  if (__syncthreads_or(open)) raster_pass<NV>(extra, lds, meta, x, y, found, val, tx0, ty0, tx1, ty1);
   if (ix < nx) {
 #pragma unroll
     for (int j = 0; j < RS_PX; ++j) {
