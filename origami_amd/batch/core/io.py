@@ -1,7 +1,7 @@
 """Artifacts of a page and their readers / writers — the part of origami/batch/core/io.py the dewarp
 and line-export stages touch (same names, file names and skip / overwrite rules).
 
-ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :92-97 (DebuggingArtifact),
+ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :92-103 (DebuggingArtifact, Annotation),
 :109-146 (read_contours), :166-224 (Regions, Lines), :227-373 (Reader), :375-387 (Input),
 :411-416 (AtomicFileWriter), :507-620 (Writer, Output).
 """
@@ -71,6 +71,11 @@ class DebuggingArtifact:  # ref: io.py:92-97
 
 	def filename(self, stage=None):
 		return self._filename
+
+
+class Annotation(DebuggingArtifact):  # ref: io.py:100-103
+	def __init__(self, name):
+		super().__init__("annotation.%s.jpg" % name)
 
 
 class PredictorType(enum.Enum):  # ref: origami/core/predict.py:136-138
@@ -348,6 +353,14 @@ class Writer:
 	def dewarping_transform(self):
 		with self._write(self.path(Artifact.DEWARPING_TRANSFORM), mode="wb") as f:
 			yield f
+
+	def annotation(self, image):
+		"""ref: io.py:606-610 (image.save to annotation.<name>.jpg); written through the atomic writer here."""
+		assert len(self._artifacts) == 1
+		annotation = list(self._artifacts)[0]
+		assert isinstance(annotation, Annotation)
+		with self._write(self.path(annotation), mode="wb") as f:
+			image.save(f, format="JPEG")
 
 
 class Output:

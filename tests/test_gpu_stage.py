@@ -197,3 +197,33 @@ def test_entry_points_are_thread_safe(gpu):
 			for (p0, t0), (p1, t1) in zip(serial, threaded):
 				np.testing.assert_array_equal(p0, p1)
 				np.testing.assert_array_equal(t0, t1)
+
+
+def test_dewarped_image_stage_matches_oracle(gpu, tmp_path):
+	"""`batch.utils.dewarp` after `batch.detect.dewarp`: annotation.dewarped.jpg is the JPEG of exactly the
+	page the oracle dewarps through the stored grid (ref: origami/batch/utils/dewarp.py:27-28)."""
+	import PIL.Image
+	from oracle import dewarp as odw2
+	from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
+	rng = np.random.default_rng(31)
+	size = (640, 480)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=100, n_v=120, n_regions=8, n_separators=2, label_size=(320, 240))
+	out = page_path.with_suffix(".out")
+	assert CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"]).exit_code == 0
+	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	info = json.loads((out / "runtime.json").read_text())
+	assert info["origami.batch.utils.dewarp"]["status"] == "COMPLETED"
+	got = PIL.Image.open(out / "annotation.dewarped.jpg")
+	grid = Grid.open(out / "dewarp.zip")
+	nodes = grid.points("sample")
+	assert got.size == (nodes.shape[1] * 25, nodes.shape[0] * 25) and got.mode == "L"
+	pixels = np.array(PIL.Image.open(page_path).convert("L"))
+	want = PIL.Image.fromarray(odw2.dewarped(pixels, odw2.Grid(nodes, 25)))
+	ref = io.BytesIO()
+	want.save(ref, format="JPEG")
+	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()  # same pixels -> same JPEG bytes
+	# done pages are skipped on a second run (output exists), redone with --overwrite
+	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0
