@@ -26,6 +26,7 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
   OGD_REQUIRE(H < 32768 && W < 32768, "%s: %dx%d exceeds the int16 coordinate range of remap", what, W, H);
   OGD_REQUIRE(C == 1 || C == 3 || C == 4, "%s: %d channels not supported (1, 3 or 4)", what, C);
   OGD_REQUIRE(stride >= (ptrdiff_t)W * C, "%s: row stride %td < %d bytes", what, stride, W * C);
+  OGD_REQUIRE(stride < (ptrdiff_t)1 << 24, "%s: row stride %td too large (the kernels address rows with 24-bit multiplies)", what, stride);
   return OGD_OK;
 }
 
@@ -36,6 +37,7 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
 // fused kernel needs 8 KB for its ~40-row window).
 template <class MapSrc> struct TileShape { static constexpr int LX = 16, RPT = 2, LDSW_MC = 6144; };
 template <> struct TileShape<MapNodes> { static constexpr int LX = 8, RPT = 4, LDSW_MC = 8192; };
+template <> struct TileShape<MapNodesUnit> : TileShape<MapNodes> {};
 
 template <int C, class MapSrc>
 static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
@@ -93,8 +95,13 @@ int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_s
   OGD_REQUIRE(d_src && d_nodes && d_dst, "null pointer");
   OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
   OGD_TRY(ensure_device());
-  const MapNodes ms{reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy, Hd, Wd};
-  launch_remap_c(C, interp, as_stream(stream), d_src, H, W, src_stride, ms, Hd, Wd, d_dst, dst_stride);
+  if (sx == 1.f && sy == 1.f) {
+    const MapNodesUnit ms{reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy, Hd, Wd};
+    launch_remap_c(C, interp, as_stream(stream), d_src, H, W, src_stride, ms, Hd, Wd, d_dst, dst_stride);
+  } else {
+    const MapNodes ms{reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy, Hd, Wd};
+    launch_remap_c(C, interp, as_stream(stream), d_src, H, W, src_stride, ms, Hd, Wd, d_dst, dst_stride);
+  }
   return check_launch("remap_u8_wave_kernel<MapNodes>");
 }
 

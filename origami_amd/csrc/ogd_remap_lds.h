@@ -38,6 +38,11 @@ typedef short rl_s2 __attribute__((ext_vector_type(2)));
 typedef const float RL_GLOBAL* rl_gf;
 typedef const rl_f4 RL_GLOBAL* rl_gf4;
 typedef const float2 RL_GLOBAL* rl_gf2;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const uint32_t __attribute__((address_space(3)))* rl_lds_u32;
+#else
+typedef const uint32_t* rl_lds_u32;
+#endif
 
 __device__ __forceinline__ rl_s2 rl_as_s2(int v) { return __builtin_bit_cast(rl_s2, v); }
 __device__ __forceinline__ int rl_as_int(rl_s2 v) { return __builtin_bit_cast(int, v); }
@@ -114,7 +119,10 @@ struct MapGlobal {
 
 // Fused K1a + K2: the map value is recomputed from the node grid (ogd_resize_math.h, bit-identical
 // to grid_fill_kernel) and scaled like dewarp_image does; the dense map never exists.
-struct MapNodes {
+// UNIT: the scale is (1, 1) (Dewarper.dewarped; v * 1.0f is v, so the multiplies are left out — a kernel of
+// its own, because as a run-time test the compiler turns it into selects over both results).
+template <bool UNIT>
+struct MapNodesT {
   const float2* __restrict__ nodes;
   int h, w;
   double inv_s;
@@ -123,6 +131,7 @@ struct MapNodes {
 
   __device__ __forceinline__ float2 at(int X, int Y) const {
     const float2 v = dense_at((rl_gf2)nodes, w, tap_x(X, inv_s, w), tap_y(Y, inv_s, h));
+    if (UNIT) return v;
     return make_float2(__fmul_rn(v.x, scx), __fmul_rn(v.y, scy));
   }
 
@@ -172,6 +181,8 @@ struct MapNodes {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int lx4 = (lane % LX) * 4, ly = lane / LX;
+      // (v_pk_mul_f32 / v_pk_add_f32 for the (x, y) pairs were measured: fewer instructions, 4 % slower —
+      // packed fp32 issues at half rate here)
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         const float4 yt = ytab[ly + r * RW];
@@ -180,10 +191,18 @@ struct MapNodes {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           const float4 p = t0[k2], q = t1[k2];  // two pixels: (x, y, x, y)
-          mv[r][4 * k2 + 0] = __fmul_rn(lerp2(p.x, yt.z, q.x, yt.w), scx);
-          mv[r][4 * k2 + 1] = __fmul_rn(lerp2(p.y, yt.z, q.y, yt.w), scy);
-          mv[r][4 * k2 + 2] = __fmul_rn(lerp2(p.z, yt.z, q.z, yt.w), scx);
-          mv[r][4 * k2 + 3] = __fmul_rn(lerp2(p.w, yt.z, q.w, yt.w), scy);
+          float ax = lerp2(p.x, yt.z, q.x, yt.w), ay = lerp2(p.y, yt.z, q.y, yt.w);
+          float bx = lerp2(p.z, yt.z, q.z, yt.w), by = lerp2(p.w, yt.z, q.w, yt.w);
+          if (!UNIT) {
+            ax = __fmul_rn(ax, scx);
+            ay = __fmul_rn(ay, scy);
+            bx = __fmul_rn(bx, scx);
+            by = __fmul_rn(by, scy);
+          }
+          mv[r][4 * k2 + 0] = ax;
+          mv[r][4 * k2 + 1] = ay;
+          mv[r][4 * k2 + 2] = bx;
+          mv[r][4 * k2 + 3] = by;
         }
       }
     }
@@ -191,6 +210,9 @@ struct MapNodes {
     return true;
   }
 };
+
+typedef MapNodesT<false> MapNodes;
+typedef MapNodesT<true> MapNodesUnit;
 
 // Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).
 template <int C, int INTERP, int LX, int RPT, class MapSrc>
@@ -351,6 +373,13 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
 
   const uint8_t* wbytes_p = reinterpret_cast<const uint8_t*>(win);
   const int base = __mul24(mny, PF) + x0b;
+  // LDS byte address of tap (cy, cx) = lp + lds_rel; slice and window origin are dword aligned, so its low two
+  // bits are the byte phase of the tap inside its dword
+  const uint32_t lds_rel = (uint32_t)(uintptr_t)(rl_lds_u32)win - (uint32_t)base;
+  // output rows: wave-uniform tile origin + 32-bit lane offsets (row strides are < 2^24: check_image)
+  uint8_t* const dtile = dst + ((ptrdiff_t)(by * TH) * ds + (ptrdiff_t)(bx * TW) * C);
+  const uint32_t ds32 = (uint32_t)ds;
+  const uint32_t dlane = __umul24((uint32_t)ly, ds32) + (uint32_t)(lx4 * C);
   // 4. gather + blend + store
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
@@ -363,9 +392,10 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
       if (LIN) {
         uint32_t top[C], bot[C];
         if (C == 1) {
-          const int i = off >> 2;
-          const uint32_t t2 = __builtin_amdgcn_alignbyte(win[i + 1], win[i], (uint32_t)off);
-          const uint32_t b2 = __builtin_amdgcn_alignbyte(win[i + PF / 4 + 1], win[i + PF / 4], (uint32_t)off);
+          const uint32_t a = (uint32_t)lp[r][k] + lds_rel;
+          const rl_lds_u32 q = (rl_lds_u32)(uintptr_t)(a & ~3u);
+          const uint32_t t2 = __builtin_amdgcn_alignbyte(q[1], q[0], a);
+          const uint32_t b2 = __builtin_amdgcn_alignbyte(q[PF / 4 + 1], q[PF / 4], a);
           top[0] = __builtin_amdgcn_udot4(t2, wa[r][k], 0u, false);
           bot[0] = __builtin_amdgcn_udot4(b2, wa[r][k], 0u, false);
         } else if (C == 3) {
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
       }
     }
     if (Y < Hd && X < Wd) {
-      uint8_t* d = dst + (ptrdiff_t)Y * ds + (ptrdiff_t)X * C;
+      uint8_t* d = dtile + (dlane + (uint32_t)(r * RW) * ds32);
       if (X + 4 <= Wd) {
 #pragma unroll
         for (int j = 0; j < 4 * C; j += 4) {

@@ -54,6 +54,19 @@ __device__ __forceinline__ float lerp2(float a, float wa, float b, float wb) {
   return __fadd_rn(__fmul_rn(a, wa), __fmul_rn(b, wb));
 }
 
+// lerp2 on an (x, y) pair: one v_pk_mul_f32 per product and a v_pk_add_f32, every element rounded exactly as
+// the scalar form rounds it
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lerp2_pk(f32x2 a, float wa, f32x2 b, float wb) {
+#pragma clang fp contract(off)
+  const f32x2 pa = a * wa, pb = b * wb;
+  return pa + pb;
+}
+__device__ __forceinline__ f32x2 mul_pk(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // Dense map value at (X, Y); nodes is [h][w] float2.
 template <class NodePtr>
 __device__ __forceinline__ float2 dense_at(NodePtr nodes, int w, const Tap& tx, const Tap& ty) {

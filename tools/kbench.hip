@@ -171,13 +171,15 @@ __global__ __launch_bounds__(256) void map_stream_tile(const float* __restrict__
 #include "../origami_amd/csrc/ogd_resize_math.h"
 template <int NT, int ROWS, int THREADS>
 __global__ __launch_bounds__(THREADS) void grid_fill_variant(const float2* __restrict__ nodes, int h, int w,
-                                                             double inv_s, float2* __restrict__ out, int Hd, int Wd) {
+                                                             double inv_s, float2* __restrict__ out, int Hd, int Wd,
+                                                             int ybeg = 0) {
+  // dense rows [ybeg, Hd) go to out rows 0 .. Hd - ybeg - 1
   const int X = (blockIdx.x * THREADS + threadIdx.x) * 2;
   if (X >= Wd) return;
   const bool pair = (X + 1 < Wd);
   const Tap tx0 = tap_x(X, inv_s, w);
   const Tap tx1 = tap_x(pair ? X + 1 : X, inv_s, w);
-  const int Y0 = blockIdx.y * ROWS, Y1 = min(Y0 + ROWS, Hd);
+  const int Y0 = ybeg + blockIdx.y * ROWS, Y1 = min(Y0 + ROWS, Hd);
   int cur0 = -1, cur1 = -1;
   float2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f}, tb0 = {0.f, 0.f}, tb1 = {0.f, 0.f};
   for (int Y = Y0; Y < Y1; ++Y) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(THREADS) void grid_fill_variant(const float2* __res
     v.y = lerp2(ta0.y, ty.w0, tb0.y, ty.w1);
     v.z = lerp2(ta1.x, ty.w0, tb1.x, ty.w1);
     v.w = lerp2(ta1.y, ty.w0, tb1.y, ty.w1);
-    float2* o = out + (size_t)Y * Wd + X;
+    float2* o = out + (size_t)(Y - ybeg) * Wd + X;
     if (!pair)
       *o = make_float2(v.x, v.y);
     else if (NT == 1)
@@ -226,13 +228,20 @@ static void run(Ctx& c, const char* name, F launch, bool check = true) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < c.iters; ++i) launch();
-  CK(hipEventRecord(e1, 0));
-  CK(hipEventSynchronize(e1));
-  float ms = 0;
-  CK(hipEventElapsedTime(&ms, e0, e1));
-  ms /= c.iters;
+  // best of KB_REPS timed loops (clocks settle over tens of ms: one short loop is good to +-5 % only)
+  const int reps = getenv("KB_REPS") ? atoi(getenv("KB_REPS")) : 1;
+  float ms = 1e30f;
+  for (int rep = 0; rep < reps; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < c.iters; ++i) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t = 0;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms = std::min(ms, t / c.iters);
+  }
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
   const double bytes = (double)c.Hd * c.Wd * 9 + (double)c.H * c.W;
   size_t bad = 0;
   if (check) {
@@ -311,6 +320,30 @@ int main(int argc, char** argv) {
       }
     });
   }
+  // the same with plain stores in K1a: the band buffer is rewritten at the same addresses band after band, so
+  // it can live in the Infinity Cache (non-temporal stores go past it)
+#define BAND_VARIANT(NT, NBANDS)                                                                          \
+  {                                                                                                       \
+    const int rows = ((c.Hd + NBANDS - 1) / NBANDS + 7) / 8 * 8;                                          \
+    run(c, "bands K1a nt=" #NT " + K2, " #NBANDS " band(s)", [&] {                                        \
+      for (int y0 = 0; y0 < c.Hd; y0 += rows) {                                                           \
+        const int n = std::min(rows, c.Hd - y0);                                                          \
+        hipLaunchKernelGGL((grid_fill_variant<NT, 4, 512>), dim3((c.Wd + 1023) / 1024, (n + 3) / 4),      \
+                           dim3(512), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, (float2*)c.map,     \
+                           y0 + n, c.Wd, y0);                                                             \
+        OK(ogd_remap_u8_dev(c.src, c.H, c.W, 1, c.W, c.map, n, c.Wd, c.dst + (size_t)y0 * c.Wd, c.Wd,     \
+                            OGD_INTER_LINEAR, nullptr));                                                  \
+      }                                                                                                   \
+    });                                                                                                   \
+  }
+  BAND_VARIANT(1, 1)
+  BAND_VARIANT(0, 1)
+  BAND_VARIANT(0, 2)
+  BAND_VARIANT(0, 3)
+  BAND_VARIANT(0, 4)
+  BAND_VARIANT(0, 6)
+  BAND_VARIANT(0, 8)
+  BAND_VARIANT(1, 4)
   OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr));
   CK(hipDeviceSynchronize());
 
@@ -388,6 +421,23 @@ int main(int argc, char** argv) {
                          (ptrdiff_t)c.Wd, nbx2, nb);                                                    \
     });                                                                                                 \
   }
+  {  // the same kernel with a non-unit scale (the multiplies by scx / scy are executed): timing only
+    const int nbx2 = (c.Wd + 31) / 32, nby = (c.Hd + 31) / 32, nb = nbx2 * nby;
+    const MapNodes mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.0000001f, 1.0000001f, c.Hd, c.Wd};
+    run(c, "fused LX=8 RPT=4 scaled map", [&] {
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodes>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+                         c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);
+    }, false);
+  }
+  {
+    const int nbx2 = (c.Wd + 31) / 32, nby = (c.Hd + 31) / 32, nb = nbx2 * nby;
+    const MapNodesUnit mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, c.Hd, c.Wd};
+    run(c, "fused LX=8 RPT=4 unit-scale kernel", [&] {
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodesUnit>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+                         c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);
+    });
+  }
+  FUSED_VARIANT(8, 4, 4096)
   FUSED_VARIANT(16, 2, 4096)
   FUSED_VARIANT(16, 4, 4096)
   FUSED_VARIANT(16, 1, 4096)
