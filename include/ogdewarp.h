@@ -95,6 +95,25 @@ int ogd_dewarp_u8_dev(const uint8_t* d_src, int H, int W, int C, ptrdiff_t src_s
                       const float* d_nodes, int h, int w, int s, float sx, float sy,
                       uint8_t* d_dst, ptrdiff_t dst_stride, int interp, void* stream);
 
+/* ---- N4: the JPEG file of a dewarped page ---------------------------------------------------------
+ * ref: origami/batch/core/io.py:606-610 (Writer.annotation: `image.save(path)` of the "L" image
+ * page.dewarped to annotation.<name>.jpg), called from origami/batch/utils/dewarp.py:27-28.  PIL hands the
+ * pixels to libjpeg(-turbo): baseline, one component, quality 75 unless given, standard Huffman tables,
+ * JFIF 1.01 header.  These entry points write that file — the same bytes — with the DCT, quantisation,
+ * Huffman coding and byte stuffing done on the device; only the code stream crosses PCIe.
+ * img: [H][W] uint8, row stride in bytes; out: host buffer of `cap` bytes; *out_size receives the size of
+ * the file (also when it does not fit: then OGD_ERR_INVALID is returned and nothing is written).
+ * ogd_dewarp_jpeg_gray = ogd_dewarp_u8 (C = 1, scale 1, linear) followed by the encoder, the dewarped page
+ * never leaves the device (what the batch stage `utils.dewarp` does per page).
+ */
+int ogd_jpeg_encode_gray(const uint8_t* img, int H, int W, ptrdiff_t stride, int quality,
+                         uint8_t* out, size_t cap, size_t* out_size);
+int ogd_jpeg_encode_gray_dev(const uint8_t* d_img, int H, int W, ptrdiff_t stride, int quality,
+                             uint8_t* out, size_t cap, size_t* out_size, void* stream);
+int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
+                         const float* nodes, int h, int w, int s, int quality,
+                         uint8_t* out, size_t cap, size_t* out_size);
+
 /* ---- K3 / K1b: piecewise-linear interpolation over a host Delaunay triangulation -------------
  * ref: origami/core/lingrid.py:286-290 (scipy LinearNDInterpolator x2), :174-189 (clip + NaN merge),
  *      :252-282 (dense variant, scipy griddata x2 + merge).

@@ -91,6 +91,12 @@ SIGNATURES = {
 	"ogd_march_grid": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
 		c_void_p, c_void_p]),
+	"ogd_jpeg_encode_gray": (c_int, [c_void_p, c_int, c_int, c_ssize_t, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
+	"ogd_jpeg_encode_gray_dev": (c_int, [
+		c_void_p, c_int, c_int, c_ssize_t, c_int, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
+	"ogd_dewarp_jpeg_gray": (c_int, [
+		c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+		POINTER(c_size_t)]),
 	"ogd_line_label_counts": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
 		c_void_p]),
@@ -224,6 +230,55 @@ def dewarp_u8(src, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
 		_ptr(src), H, W, C, src.strides[0], _ptr(nodes), h, w, int(cell), float(sx), float(sy),
 		_ptr(dst), dst.strides[0], int(interpolation)))
 	return dst[:, :, 0] if squeeze else dst
+
+
+# ---- JPEG files (N4) ---------------------------------------------------------------------------------
+
+def _jpeg_call(call, pixels_hint):
+	"""Runs an encoder entry point into a buffer sized from the pixel count (JPEG at quality 75 stays
+	far below half a byte per pixel); retried once with the exact size if a page is denser."""
+	cap = max(4096, pixels_hint // 2 + 1024)
+	for _ in range(2):
+		out = np.empty(cap, dtype=np.uint8)
+		size = c_size_t(0)
+		status = call(_ptr(out), cap, ctypes.byref(size))
+		if status == 0:
+			return out[:size.value].tobytes()
+		if size.value <= cap:
+			check(status)
+		cap = size.value
+	check(status)
+
+
+def jpeg_encode_gray(pixels, quality=75):
+	"""The bytes PIL writes for Image.fromarray(pixels).save(f, "JPEG", quality=quality) ("L" image)."""
+	a = np.asarray(pixels)
+	if a.dtype != np.uint8 or a.ndim != 2:
+		raise TypeError("jpeg_encode_gray takes a (H, W) uint8 array")
+	if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
+		a = np.ascontiguousarray(a)
+	H, W = a.shape
+	lib = load()
+	return _jpeg_call(
+		lambda out, cap, size: lib.ogd_jpeg_encode_gray(_ptr(a), H, W, a.strides[0], int(quality), out, cap, size),
+		H * W)
+
+
+def dewarp_jpeg_gray(src, nodes, cell, quality=75):
+	"""dewarp_u8 of a gray page followed by jpeg_encode_gray, the dewarped pixels staying on the device."""
+	a = np.asarray(src)
+	if a.dtype != np.uint8 or a.ndim != 2:
+		raise TypeError("dewarp_jpeg_gray takes a (H, W) uint8 page")
+	if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
+		a = np.ascontiguousarray(a)
+	nodes = _c(nodes, np.float32)
+	H, W = a.shape
+	h, w = nodes.shape[:2]
+	lib = load()
+	return _jpeg_call(
+		lambda out, cap, size: lib.ogd_dewarp_jpeg_gray(
+			_ptr(a), H, W, a.strides[0], _ptr(nodes), h, w, int(cell), int(quality), out, cap, size),
+		h * cell * w * cell)
 
 
 # ---- resident pages, per-line images (N1) ---------------------------------------------------------

@@ -360,7 +360,10 @@ class Writer:
 		annotation = list(self._artifacts)[0]
 		assert isinstance(annotation, Annotation)
 		with self._write(self.path(annotation), mode="wb") as f:
-			image.save(f, format="JPEG")
+			if isinstance(image, (bytes, bytearray, memoryview)):
+				f.write(image)  # an already encoded file (Page.dewarped_jpeg: the device-side encoder)
+			else:
+				image.save(f, format="JPEG")
 
 
 class Output:

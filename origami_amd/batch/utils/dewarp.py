@@ -4,7 +4,8 @@
 
 The one stage of the reference that does nothing but the pixel hot loop: Reader.page opens the page with
 its dewarping transform (ref: origami/batch/core/io.py:275-280, origami/core/page.py:82-88) and the page
-goes through the fused grid-fill + remap kernel (ogd_dewarp_u8) on first use of `page.dewarped`."""
+goes through the fused grid-fill + remap kernel and the device-side JPEG encoder (ogd_dewarp_jpeg_gray): the
+file is the one PIL writes for `page.dewarped`, byte for byte, and only its ~0.14 B/px cross PCIe."""
 
 from pathlib import Path
 
@@ -30,7 +31,8 @@ class DewarpProcessor(Processor):
 		]
 
 	def process(self, page_path: Path, dewarped, output):
-		output.annotation(dewarped.page.dewarped)
+		# the reference saves the PIL image dewarped.page.dewarped; the same file comes encoded from the device
+		output.annotation(dewarped.page.dewarped_jpeg())
 
 
 @click.command()

@@ -394,6 +394,15 @@ class Dewarper:
 				interpolation=INTER_LINEAR))
 		return self._dewarped
 
+	def dewarped_jpeg(self, quality=75):
+		"""The file `self.dewarped.save(path.jpg)` writes (ref: origami/batch/core/io.py:606-610), as bytes:
+		dewarp and JPEG encoding both run on the device (ogd_dewarp_jpeg_gray), only the code stream comes
+		back.  Gray pages only (Page converts to "L", ref: origami/core/page.py:84)."""
+		if self._im.mode != "L":
+			raise ValueError("dewarped_jpeg needs an 'L' page, got mode %s" % self._im.mode)
+		return _shim.dewarp_jpeg_gray(
+			np.array(self._im), self._grid.points("sample"), self._grid.resolution, quality=quality)
+
 	def dewarp_image(self, im, interpolation=INTER_LINEAR):
 		"""Remap an image of any size (label map, RGB page) through the page's grid, scaled by
 		the size ratio.  The reference multiplies its cached dense grid in place (dewarp.py:621-623),

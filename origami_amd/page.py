@@ -58,6 +58,10 @@ class Page:
 	def dewarped(self):
 		return self.dewarper.dewarped if self._grid is not None else None
 
+	def dewarped_jpeg(self, quality=75):
+		"""`self.dewarped` as the JPEG file PIL would save (bytes), encoded on the device."""
+		return self.dewarper.dewarped_jpeg(quality) if self._grid is not None else None
+
 	def size(self, dewarped):
 		if dewarped:
 			return self.dewarped.size

@@ -404,6 +404,14 @@ int main(int argc, char** argv) {
                          c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                                                                    \
     });                                                                                                 \
   }
+  {  // nearest sampling through the same map: the memory side of K2 with a fraction of its integer work
+    const int nbx2 = (c.Wd + 63) / 64, nby = (c.Hd + 7) / 8, nb = nbx2 * nby;
+    run(c, "wave LX=16 RPT=2 nearest", [&] {
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 0, 16, 2, 4096, MapGlobal>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+                         c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd}, c.Hd, c.Wd, c.dst,
+                         (ptrdiff_t)c.Wd, nbx2, nb);
+    }, false);
+  }
   WAVE_VARIANT(16, 2, 4096)
   WAVE_VARIANT(16, 2, 8192)
   WAVE_VARIANT(16, 4, 4096)
