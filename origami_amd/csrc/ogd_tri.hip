@@ -304,59 +304,160 @@ struct BucketGeom {
   double bx0, by0, cw, ch, mx, my;
 };
 
+// One cell of one triangle's cell rectangle: count or fill.
+template <bool FILL>
+__device__ __forceinline__ int bucket_visit(const BucketGeom& g, const double* X, const double* Y, bool one, int cx, int cy,
+                                            int t, int* __restrict__ counter, int* __restrict__ cell_tris) {
+  const double rx0 = g.bx0 + cx * g.cw - g.mx, rx1 = g.bx0 + (cx + 1) * g.cw + g.mx;
+  const double ry0 = g.by0 + cy * g.ch - g.my, ry1 = g.by0 + (cy + 1) * g.ch + g.my;
+  if (!one && tri_misses_rect(X, Y, rx0, ry0, rx1, ry1)) return 0;
+  const int c = cy * g.gnx + cx;
+  if (FILL)
+    cell_tris[atomicAdd(&counter[c], 1)] = t;  // counter = running cursor of the cell
+  else
+    atomicAdd(&counter[c + 1], 1);  // counter[c + 1] = list length of cell c
+  return 1;
+}
+
+// The cell rectangle of triangle t (empty for a degenerate simplex).
+struct TriRect {
+  double X[3], Y[3];
+  int cx0, cy0, wdt;
+  long long ncells;
+};
+__device__ __forceinline__ TriRect tri_rect(const double2* __restrict__ pts, const int32_t* __restrict__ simplices,
+                                            const double* __restrict__ rec, int reclen, const BucketGeom& g, int t) {
+  TriRect q;
+  q.cx0 = q.cy0 = 0;
+  q.wdt = 0;
+  q.ncells = 0;
+  for (int k = 0; k < 3; ++k) q.X[k] = q.Y[k] = 0;
+  const double* r = rec + (size_t)t * reclen;
+  for (int k = 0; k < 6; ++k)
+    if (!isfinite(r[k])) return q;  // degenerate simplex: never contains a point
+  const int32_t* s = simplices + 3 * (size_t)t;
+  const double2 p0 = pts[s[0]], p1 = pts[s[1]], p2 = pts[s[2]];
+  q.X[0] = p0.x; q.X[1] = p1.x; q.X[2] = p2.x;
+  q.Y[0] = p0.y; q.Y[1] = p1.y; q.Y[2] = p2.y;
+  const double tx0 = fmin(fmin(p0.x, p1.x), p2.x) - g.mx, tx1 = fmax(fmax(p0.x, p1.x), p2.x) + g.mx;
+  const double ty0 = fmin(fmin(p0.y, p1.y), p2.y) - g.my, ty1 = fmax(fmax(p0.y, p1.y), p2.y) + g.my;
+  q.cx0 = min(g.gnx - 1, max(0, (int)floor((tx0 - g.bx0) / g.cw)));
+  const int cx1 = min(g.gnx - 1, max(0, (int)floor((tx1 - g.bx0) / g.cw)));
+  q.cy0 = min(g.gny - 1, max(0, (int)floor((ty0 - g.by0) / g.ch)));
+  const int cy1 = min(g.gny - 1, max(0, (int)floor((ty1 - g.by0) / g.ch)));
+  q.wdt = cx1 - q.cx0 + 1;
+  q.ncells = (long long)q.wdt * (cy1 - q.cy0 + 1);
+  return q;
+}
+
+// Thread per triangle for the usual few-cell rectangles.  A triangle whose rectangle holds more than
+// BUCKET_WAVE_MIN cells (the slivers of an extrapolation set, or of the pockets between a warped lattice and its
+// hull: thousands of cells each, and neighbours in index, so that a few wavefronts would walk them all while
+// the launch waits) goes on a list in the counting pass; bucket_big_kernel walks each with a wavefront of its own.
+constexpr int BUCKET_WAVE_MIN = 48;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const double2* __restrict__ pts,
                                                              const int32_t* __restrict__ simplices,
                                                              const double* __restrict__ rec, int reclen, int nt,
                                                              BucketGeom g, int* __restrict__ counter,
                                                              int* __restrict__ cell_tris,
-                                                             unsigned long long* __restrict__ total) {
+                                                             unsigned long long* __restrict__ total,
+                                                             int* __restrict__ big_list, int* __restrict__ nbig) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nt) return;
-  const double* r = rec + (size_t)t * reclen;
-  for (int k = 0; k < 6; ++k)
-    if (!isfinite(r[k])) return;  // degenerate simplex: never contains a point
-  const int32_t* s = simplices + 3 * (size_t)t;
-  const double2 p0 = pts[s[0]], p1 = pts[s[1]], p2 = pts[s[2]];
-  const double X[3] = {p0.x, p1.x, p2.x}, Y[3] = {p0.y, p1.y, p2.y};
-  const double tx0 = fmin(fmin(X[0], X[1]), X[2]) - g.mx, tx1 = fmax(fmax(X[0], X[1]), X[2]) + g.mx;
-  const double ty0 = fmin(fmin(Y[0], Y[1]), Y[2]) - g.my, ty1 = fmax(fmax(Y[0], Y[1]), Y[2]) + g.my;
-  const int cx0 = min(g.gnx - 1, max(0, (int)floor((tx0 - g.bx0) / g.cw)));
-  const int cx1 = min(g.gnx - 1, max(0, (int)floor((tx1 - g.bx0) / g.cw)));
-  const int cy0 = min(g.gny - 1, max(0, (int)floor((ty0 - g.by0) / g.ch)));
-  const int cy1 = min(g.gny - 1, max(0, (int)floor((ty1 - g.by0) / g.ch)));
-  const bool one = cx1 == cx0 && cy1 == cy0;
+  const TriRect q = tri_rect(pts, simplices, rec, reclen, g, t);
+  if (q.ncells == 0) return;
+  if (q.ncells > BUCKET_WAVE_MIN) {
+    if (!FILL) big_list[atomicAdd(nbig, 1)] = t;
+    return;
+  }
+  const bool one = q.ncells == 1;
+  const int hgt = (int)(q.ncells / q.wdt);
   unsigned long long mine = 0;
-  for (int cy = cy0; cy <= cy1; ++cy)
-    for (int cx = cx0; cx <= cx1; ++cx) {
-      const double rx0 = g.bx0 + cx * g.cw - g.mx, rx1 = g.bx0 + (cx + 1) * g.cw + g.mx;
-      const double ry0 = g.by0 + cy * g.ch - g.my, ry1 = g.by0 + (cy + 1) * g.ch + g.my;
-      if (!one && tri_misses_rect(X, Y, rx0, ry0, rx1, ry1)) continue;
-      const int c = cy * g.gnx + cx;
-      if (FILL)
-        cell_tris[atomicAdd(&counter[c], 1)] = t;  // counter = running cursor of the cell
-      else
-        atomicAdd(&counter[c + 1], 1);  // counter[c + 1] = list length of cell c
-      ++mine;
-    }
+  for (int ry = 0; ry < hgt; ++ry)
+    for (int rx = 0; rx < q.wdt; ++rx)
+      mine += bucket_visit<FILL>(g, q.X, q.Y, one, q.cx0 + rx, q.cy0 + ry, t, counter, cell_tris);
   if (!FILL) atomicAdd(total, mine);  // 64-bit sum of all list lengths: the host refuses a grid past INT_MAX
 }
 
+template <bool FILL>
+__global__ __launch_bounds__(256) void bucket_big_kernel(const double2* __restrict__ pts,
+                                                         const int32_t* __restrict__ simplices,
+                                                         const double* __restrict__ rec, int reclen, BucketGeom g,
+                                                         int* __restrict__ counter, int* __restrict__ cell_tris,
+                                                         unsigned long long* __restrict__ total,
+                                                         const int* __restrict__ big_list, int nbig) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= nbig) return;  // wave-uniform
+  const int t = big_list[k];
+  const TriRect q = tri_rect(pts, simplices, rec, reclen, g, t);
+  unsigned long long mine = 0;
+  for (long long i = lane; i < q.ncells; i += 64) {
+    const int ry = (int)(i / q.wdt), rx = (int)(i - (long long)ry * q.wdt);
+    mine += bucket_visit<FILL>(g, q.X, q.Y, false, q.cx0 + rx, q.cy0 + ry, t, counter, cell_tris);
+  }
+  if (!FILL && mine) atomicAdd(total, mine);
+}
+
+// Ascending triangle index inside every cell.  Most lists hold a handful of entries (insertion sort by the
+// cell's thread); a cell under a fan of slivers holds hundreds, and is left to bucket_sort_long_kernel.
+constexpr int BUCKET_SORT_LONG = 24;
+constexpr int BUCKET_SORT_LDS = 2048;  // entries a wavefront ranks through LDS
+
+__device__ __forceinline__ void insertion_sort(int* __restrict__ a, int b, int e) {
+  for (int i = b + 1; i < e; ++i) {
+    const int v = a[i];
+    int j = i - 1;
+    while (j >= b && a[j] > v) {
+      a[j + 1] = a[j];
+      --j;
+    }
+    a[j + 1] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const int* __restrict__ cell_start, int ncell,
-                                                          int* __restrict__ cell_tris, int* __restrict__ max_cell) {
+                                                          int* __restrict__ cell_tris, int* __restrict__ max_cell,
+                                                          int* __restrict__ long_cells, int* __restrict__ nlong) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncell) return;
   const int b = cell_start[c], e = cell_start[c + 1];
-  for (int i = b + 1; i < e; ++i) {  // insertion sort: the lists hold a handful of entries
-    const int v = cell_tris[i];
-    int j = i - 1;
-    while (j >= b && cell_tris[j] > v) {
-      cell_tris[j + 1] = cell_tris[j];
-      --j;
-    }
-    cell_tris[j + 1] = v;
-  }
+  if (e - b > BUCKET_SORT_LONG)
+    long_cells[atomicAdd(nlong, 1)] = c;
+  else
+    insertion_sort(cell_tris, b, e);
   if (e - b > 1) atomicMax(max_cell, e - b);
+}
+
+// One wavefront per long list: the entries are distinct, so the rank of an entry is the number of smaller ones.
+__global__ __launch_bounds__(256) void bucket_sort_long_kernel(const int* __restrict__ cell_start,
+                                                               int* __restrict__ cell_tris,
+                                                               const int* __restrict__ long_cells,
+                                                               const int* __restrict__ nlong) {
+  __shared__ int s_all[4][BUCKET_SORT_LDS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* sv = s_all[wave];
+  const int n = *nlong, nwaves = gridDim.x * 4;
+  for (int k = blockIdx.x * 4 + wave; k < n; k += nwaves) {  // wave-uniform
+    const int c = long_cells[k];
+    const int b = cell_start[c], len = cell_start[c + 1] - b;
+    if (len > BUCKET_SORT_LDS) {  // pathological: thousands of triangles over one cell
+      if (lane == 0) insertion_sort(cell_tris, b, b + len);
+      continue;
+    }
+    for (int i = lane; i < len; i += 64) sv[i] = cell_tris[b + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < len; i += 64) {
+      const int v = sv[i];
+      int rank = 0;
+      for (int j = 0; j < len; ++j) rank += sv[j] < v;
+      cell_tris[b + rank] = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // sv is re-used by the next list
+  }
 }
 
 template <class T>
@@ -454,20 +555,33 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
   h->inv_cw = 1.0 / cw; h->inv_ch = 1.0 / ch;
   auto build = [&]() -> int {
     OGD_TRY(upload(&h->d_rec, recs));
-    DevBuf dpts, dsimp, dcursor, dscalars;
+    DevBuf dpts, dsimp, dcursor, dscalars, dbig;
     OGD_TRY(dpts.alloc((size_t)n * 2 * sizeof(double)));
     OGD_TRY(dsimp.alloc((size_t)nt * 3 * sizeof(int32_t)));
     OGD_TRY(dcursor.alloc((size_t)ncell * sizeof(int)));
-    OGD_TRY(dscalars.alloc(16));  // long long total | int max_cell
+    OGD_TRY(dscalars.alloc(32));  // long long total | int max_cell | int nbig | int nlong
+    OGD_TRY(dbig.alloc((size_t)nt * sizeof(int)));
     OGD_HIP(hipMemcpy(dpts.p, pts, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
     OGD_HIP(hipMemcpy(dsimp.p, simplices, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
     OGD_HIP(hipMalloc((void**)&h->d_cell_start, (size_t)(ncell + 1) * sizeof(int)));
     OGD_HIP(hipMemsetAsync(h->d_cell_start, 0, (size_t)(ncell + 1) * sizeof(int), nullptr));
-    OGD_HIP(hipMemsetAsync(dscalars.p, 0, 16, nullptr));
+    OGD_HIP(hipMemsetAsync(dscalars.p, 0, 32, nullptr));
+    unsigned long long* d_total = dscalars.as<unsigned long long>();
+    int* d_nbig = reinterpret_cast<int*>(dscalars.as<char>() + 12);
     const dim3 tgrid((unsigned)((nt + 255) / 256)), tblock(256);
     hipLaunchKernelGGL(bucket_scatter_kernel<false>, tgrid, tblock, 0, nullptr, dpts.as<double2>(),
-                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, dscalars.as<unsigned long long>());
+                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, d_total,
+                       dbig.as<int>(), d_nbig);
     OGD_TRY(check_launch("bucket_scatter_kernel<count>"));
+    int nbig = 0;
+    OGD_HIP(hipMemcpy(&nbig, d_nbig, sizeof nbig, hipMemcpyDeviceToHost));
+    OGD_REQUIRE(nbig >= 0 && nbig <= nt, "bucket grid: %d large triangles of %d", nbig, nt);
+    const dim3 bgrid((unsigned)((nbig + 3) / 4));
+    if (nbig > 0) {
+      hipLaunchKernelGGL(bucket_big_kernel<false>, bgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
+                         h->d_rec, rec, geom, h->d_cell_start, (int*)nullptr, d_total, dbig.as<int>(), nbig);
+      OGD_TRY(check_launch("bucket_big_kernel<count>"));
+    }
     unsigned long long total64 = 0;
     OGD_HIP(hipMemcpy(&total64, dscalars.p, sizeof total64, hipMemcpyDeviceToHost));
     OGD_REQUIRE(total64 < (unsigned long long)INT_MAX, "bucket grid overflow");
@@ -483,12 +597,24 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     OGD_HIP(hipMalloc((void**)&h->d_cell_tris, (size_t)std::max(total, 1) * sizeof(int)));
     OGD_HIP(hipMemcpyAsync(dcursor.p, h->d_cell_start, (size_t)ncell * sizeof(int), hipMemcpyDeviceToDevice, nullptr));
     hipLaunchKernelGGL(bucket_scatter_kernel<true>, tgrid, tblock, 0, nullptr, dpts.as<double2>(),
-                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, dcursor.as<int>(), h->d_cell_tris, (unsigned long long*)nullptr);
+                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, dcursor.as<int>(), h->d_cell_tris,
+                       (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr);
     OGD_TRY(check_launch("bucket_scatter_kernel<fill>"));
+    if (nbig > 0) {
+      hipLaunchKernelGGL(bucket_big_kernel<true>, bgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
+                         h->d_rec, rec, geom, dcursor.as<int>(), h->d_cell_tris, (unsigned long long*)nullptr,
+                         dbig.as<int>(), nbig);
+      OGD_TRY(check_launch("bucket_big_kernel<fill>"));
+    }
     int* d_max = reinterpret_cast<int*>(dscalars.as<char>() + 8);
+    int* d_nlong = reinterpret_cast<int*>(dscalars.as<char>() + 16);
+    // the fill cursors are spent: their buffer takes the list of long cells
     hipLaunchKernelGGL(bucket_sort_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, nullptr,
-                       h->d_cell_start, (int)ncell, h->d_cell_tris, d_max);
+                       h->d_cell_start, (int)ncell, h->d_cell_tris, d_max, dcursor.as<int>(), d_nlong);
     OGD_TRY(check_launch("bucket_sort_kernel"));
+    hipLaunchKernelGGL(bucket_sort_long_kernel, dim3(256), dim3(256), 0, nullptr, h->d_cell_start, h->d_cell_tris,
+                       dcursor.as<int>(), d_nlong);
+    OGD_TRY(check_launch("bucket_sort_long_kernel"));
     int max_cell = 0;
     OGD_HIP(hipMemcpy(&max_cell, d_max, sizeof max_cell, hipMemcpyDeviceToHost));  // also: the build is complete
     h->max_cell = std::max(max_cell, total > 0 ? 1 : 0);
