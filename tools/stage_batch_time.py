@@ -50,6 +50,24 @@ def main():
 		mp = n_pages * W * H / 1e6
 		print("second pass: %.3f s = %.1f ms/page = %.0f MP/s (page megapixels per second through the stage)" % (
 			dt, 1e3 * dt / n_pages, mp / dt))
+		# the stage that writes annotation.dewarped.jpg from dewarp.zip (ref: origami/batch/utils/dewarp.py)
+		from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
+
+		def run_image_stage():
+			args = [str(root), "--lock-strategy", "NONE", "--plain", "--overwrite"] + (["--gpus", str(workers)] if workers else [])
+			t = time.perf_counter()
+			res = CliRunner().invoke(dewarp_image_stage, args)
+			assert res.exit_code == 0, res.output
+			return time.perf_counter() - t
+
+		run_image_stage()
+		dt = run_image_stage()
+		import PIL.Image
+		t = time.perf_counter()
+		PIL.Image.open(first).convert("L").load()
+		t_dec = time.perf_counter() - t
+		print("utils.dewarp stage (page PNG -> annotation.dewarped.jpg): %.3f s = %.1f ms/page, of which PIL decodes the page for %.1f ms" % (
+			dt, 1e3 * dt / n_pages, 1e3 * t_dec))
 		if not workers:
 			pr = cProfile.Profile()
 			pr.enable()
