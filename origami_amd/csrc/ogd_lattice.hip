@@ -267,12 +267,31 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   const int nt = (int)(T.size() / 3);
   std::vector<int32_t> N((size_t)3 * nt, -1);
   {
+    // Nearly every edge joins lattice neighbours: hi - lo is 1, w - 1, w or w + 1, so (lo, which of the four)
+    // addresses a table directly; only the few edges inside the hull pockets go through a sort.
     struct HalfEdge { uint64_t key; int32_t slot; };
-    std::vector<HalfEdge> he((size_t)3 * nt);
+    std::vector<HalfEdge> he;
+    std::vector<int32_t> first((size_t)4 * n, -1);  // -1: not seen, -2: already paired, else the first slot
     for (int t = 0; t < nt; ++t)
       for (int k = 0; k < 3; ++k) {
         const uint32_t a = (uint32_t)T[3 * t + (k + 1) % 3], b = (uint32_t)T[3 * t + (k + 2) % 3];
-        he[(size_t)3 * t + k] = {((uint64_t)std::min(a, b) << 32) | std::max(a, b), 3 * t + k};
+        const uint32_t lo = std::min(a, b), hi = std::max(a, b), diff = hi - lo;
+        const int code = diff == 1u ? 0 : diff == (uint32_t)w - 1u ? 1 : diff == (uint32_t)w ? 2 : diff == (uint32_t)w + 1u ? 3 : -1;
+        const int32_t slot = 3 * t + k;
+        if (code < 0 || w < 3) {  // w = 2: the four differences are not distinct
+          he.push_back({((uint64_t)lo << 32) | hi, slot});
+          continue;
+        }
+        int32_t& f = first[(size_t)4 * lo + code];
+        if (f == -1) {
+          f = slot;
+        } else if (f >= 0) {
+          N[f] = slot / 3;
+          N[slot] = f / 3;
+          f = -2;
+        } else {
+          OGD_UNSUPPORTED("edge shared by three triangles");
+        }
       }
     std::sort(he.begin(), he.end(), [](const HalfEdge& x, const HalfEdge& y) { return x.key < y.key; });
     for (size_t k = 0; k + 1 < he.size(); ++k)
