@@ -114,6 +114,20 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
                          const float* nodes, int h, int w, int s, int quality,
                          uint8_t* out, size_t cap, size_t* out_size);
 
+/* ---- N4: decoding the page image ------------------------------------------------------------------
+ * ref: origami/core/page.py:82-84 (`PIL.Image.open(path).convert("L")`).  A baseline JPEG decoder on the device
+ * for 8-bit, one-component (grayscale) Huffman files without restart markers: the pixels PIL / libjpeg-turbo
+ * decode, bit for bit (Huffman decoding in parallel by fixed-point iteration over 1024-bit chunks, islow IDCT).
+ * ogd_jpeg_info: size and component count of any JPEG file; *supported = 1 if this decoder covers it (else
+ * ogd_last_error() names the reason and the caller keeps its own decoder — colour, progressive, DRI ...).
+ * ogd_jpeg_decode_gray: file bytes -> [H][W] uint8 (host, row stride in bytes); OGD_ERR_UNSUPPORTED for a file
+ * outside the decoder's domain, OGD_ERR_RUNTIME for a scan with too few blocks.  _dev: output in device memory.
+ */
+int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* supported);
+int ogd_jpeg_decode_gray(const uint8_t* file, size_t n, uint8_t* out, int H, int W, ptrdiff_t stride);
+int ogd_jpeg_decode_gray_dev(const uint8_t* file, size_t n, uint8_t* d_out, int H, int W, ptrdiff_t stride,
+                             void* stream);
+
 /* ---- K3 / K1b: piecewise-linear interpolation over a host Delaunay triangulation -------------
  * ref: origami/core/lingrid.py:286-290 (scipy LinearNDInterpolator x2), :174-189 (clip + NaN merge),
  *      :252-282 (dense variant, scipy griddata x2 + merge).

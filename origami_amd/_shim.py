@@ -97,6 +97,9 @@ SIGNATURES = {
 	"ogd_dewarp_jpeg_gray": (c_int, [
 		c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
 		POINTER(c_size_t)]),
+	"ogd_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+	"ogd_jpeg_decode_gray": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t]),
+	"ogd_jpeg_decode_gray_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t, c_void_p]),
 	"ogd_line_label_counts": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
 		c_void_p]),
@@ -279,6 +282,29 @@ def dewarp_jpeg_gray(src, nodes, cell, quality=75):
 		lambda out, cap, size: lib.ogd_dewarp_jpeg_gray(
 			_ptr(a), H, W, a.strides[0], _ptr(nodes), h, w, int(cell), int(quality), out, cap, size),
 		h * cell * w * cell)
+
+
+def jpeg_info(data):
+	"""(H, W, components, supported) of a JPEG file held in `data` (bytes)."""
+	buf = np.frombuffer(data, dtype=np.uint8)
+	H, W, nc, ok = c_int(0), c_int(0), c_int(0), c_int(0)
+	check(load().ogd_jpeg_info(_ptr(buf), buf.size, ctypes.byref(H), ctypes.byref(W), ctypes.byref(nc), ctypes.byref(ok)))
+	return H.value, W.value, nc.value, bool(ok.value)
+
+
+def jpeg_decode_gray(data):
+	"""np.array(PIL.Image.open(file)) for a baseline grayscale JPEG, decoded on the device; None if the file is
+	outside the decoder's domain (colour, progressive, restart intervals ...: the caller keeps PIL)."""
+	buf = np.frombuffer(data, dtype=np.uint8)
+	H, W, nc, ok = jpeg_info(data)
+	if not ok:
+		return None
+	out = np.empty((H, W), dtype=np.uint8)
+	status = load().ogd_jpeg_decode_gray(_ptr(buf), buf.size, _ptr(out), H, W, out.strides[0])
+	if status == ERR_UNSUPPORTED:
+		return None
+	check(status)
+	return out
 
 
 # ---- resident pages, per-line images (N1) ---------------------------------------------------------

@@ -1,0 +1,632 @@
+// N4 — decoding the page image (ref: origami/core/page.py:82-84, `PIL.Image.open(path).convert("L")`): the
+// 0.15 - 0.2 s libjpeg spends per broadsheet scan are what every stage that opens a page pays first.
+// This is a baseline JPEG decoder for one-component (grayscale) 8-bit Huffman files without restart markers;
+// its pixels are the ones PIL / libjpeg-turbo produce, bit for bit (tests/ compare with PIL itself).  Anything
+// else (colour, progressive, arithmetic coding, 12 bit, DRI) returns OGD_ERR_UNSUPPORTED and the caller keeps PIL.
+//
+// Restated from ITU T.81 and libjpeg's conventions: Huffman decoding (F.2.2), DC prediction, dequantisation,
+// inverse DCT "islow" (13-bit constants, 2 extra bits after the column pass, final shift by 18), sample =
+// range_limit[(v >> 18 rounded) & 1023] with libjpeg's table (wraps, does not clamp, beyond +-384).
+//
+// The entropy-coded segment is one long bit string; where a block starts is known only by decoding everything
+// before it.  It is decoded in parallel all the same, by iterating to a fixed point:
+//   D1 unstuff        0xFF 0x00 -> 0xFF (count per 4 KB chunk, scan, compact)
+//   D2 decode_chunks  thread per 1024-bit chunk: starts from the state (bit position, coefficient index) at
+//                     which its predecessor LEFT its chunk in the previous round (round 0: the chunk border,
+//                     index 0), decodes to the end of its own chunk and publishes its exit state.  Chunk 0 always
+//                     starts right, so after round r chunks 0..r are exact; Huffman streams re-synchronise
+//                     within a few dozen symbols, so in practice everything is exact after a handful of
+//                     rounds.  The host stops when a round changes no state.
+//   D3 scan of the blocks completed per chunk -> first block of every chunk
+//   D4 decode_chunks<WRITE>  the same walk, now storing DC differences and AC coefficients
+//   D5 inclusive scan of the DC differences (hipCUB), D6 idct_kernel: thread per 8x8 block
+#include "ogd_common.h"
+#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <vector>
+
+namespace ogd {
+namespace {
+
+constexpr int CHUNK_BITS = 1024;
+constexpr int UN_CHUNK = 4096;
+
+struct DecHuff {        // one Huffman table, decoder form
+  uint16_t look8[256];  // len << 8 | symbol for codes of <= 8 bits, 0 otherwise
+  int32_t maxcode[17];  // largest code of length l (-1: none)
+  int32_t valoff[17];   // symbol index of the first code of length l, minus that code
+  uint8_t vals[256];
+};
+struct DecTables {
+  DecHuff dc, ac;
+  uint16_t quant[64];  // natural order
+};
+
+static bool build_dec_huff(const uint8_t* bits, const uint8_t* vals, int nvals, DecHuff& h) {
+  std::memset(&h, 0, sizeof h);
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    h.valoff[l] = k - code;
+    h.maxcode[l] = -1;
+    for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
+      if (k >= nvals || code >= (1 << l)) return false;
+      if (l <= 8) {
+        const int lo = code << (8 - l), hi = lo + (1 << (8 - l));
+        for (int c = lo; c < hi; ++c) h.look8[c] = (uint16_t)((l << 8) | vals[k]);
+      }
+      h.maxcode[l] = code;
+    }
+    code <<= 1;
+  }
+  if (k != nvals) return false;
+  std::memcpy(h.vals, vals, (size_t)nvals);
+  return true;
+}
+
+// ---- D1 ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool is_stuffing(const uint8_t* __restrict__ raw, uint64_t i) {
+  return i > 0 && raw[i] == 0 && raw[i - 1] == 0xFF;
+}
+
+__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ raw, uint64_t n, int nchunk,
+                                                            uint64_t* __restrict__ counts) {
+  typedef hipcub::BlockReduce<int, 256> Reduce;
+  __shared__ typename Reduce::TempStorage tmp;
+  const int ch = blockIdx.x;
+  int c = 0;
+  if (ch < nchunk) {
+    const uint64_t i0 = (uint64_t)ch * UN_CHUNK + threadIdx.x * 16;
+    for (int k = 0; k < 16; ++k)
+      if (i0 + k < n) c += is_stuffing(raw, i0 + k);
+  }
+  const int total = Reduce(tmp).Sum(c);
+  if (threadIdx.x == 0) counts[ch] = ch < nchunk ? (uint64_t)total : 0;  // counts[nchunk]: sentinel
+}
+
+__global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __restrict__ raw, uint64_t n,
+                                                              const uint64_t* __restrict__ removed_before,
+                                                              uint8_t* __restrict__ out) {
+  typedef hipcub::BlockScan<int, 256> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  const uint64_t i0 = (uint64_t)blockIdx.x * UN_CHUNK + threadIdx.x * 16;
+  int c = 0;
+  uint32_t drop = 0;
+  for (int k = 0; k < 16; ++k)
+    if (i0 + k < n && is_stuffing(raw, i0 + k)) {
+      drop |= 1u << k;
+      ++c;
+    }
+  int before = 0;
+  Scan(tmp).ExclusiveSum(c, before);
+  uint64_t o = i0 - removed_before[blockIdx.x] - (uint64_t)before;
+  for (int k = 0; k < 16 && i0 + k < n; ++k)
+    if (!(drop >> k & 1)) out[o++] = raw[i0 + k];
+}
+
+// ---- D2 / D4 -------------------------------------------------------------------------------------------
+
+// 64 bits of the stream starting at the byte that holds bit p (the buffer is padded with zero bytes)
+__device__ __forceinline__ uint64_t window(const uint8_t* __restrict__ s, uint64_t p) {
+  typedef uint64_t u64u __attribute__((aligned(1)));
+  const uint64_t w = *reinterpret_cast<const u64u*>(s + (p >> 3));
+  return __builtin_bswap64(w) << (p & 7);  // >= 57 valid bits at the top
+}
+
+// One Huffman symbol from the top of `w`: returns the symbol, `len` = code length (an impossible code,
+// seen only on a speculative walk, is taken as symbol 0 of 16 bits: any deterministic choice will do).
+__device__ __forceinline__ int decode_symbol(const uint16_t* __restrict__ look8, const int32_t* __restrict__ maxcode,
+                                             const int32_t* __restrict__ valoff, const uint8_t* __restrict__ vals,
+                                             uint64_t w, int& len) {
+  const uint32_t c16 = (uint32_t)(w >> 48);
+  const uint32_t e = look8[c16 >> 8];
+  if (e) {
+    len = (int)(e >> 8);
+    return (int)(e & 255u);
+  }
+  for (int l = 9; l <= 16; ++l) {
+    const int c = (int)(c16 >> (16 - l));
+    if (c <= maxcode[l]) {
+      len = l;
+      return vals[(c + valoff[l]) & 255];
+    }
+  }
+  len = 16;
+  return 0;
+}
+
+struct ChunkState {
+  uint64_t p;  // bit position of the next symbol
+  int32_t k;   // index of the next coefficient of the current block (0: a DC symbol comes next)
+  int32_t pad;
+};
+
+// Walks chunk `i` from the exit state of chunk i - 1.  WRITE = false: publishes the exit state (and whether it
+// changed) and the number of blocks completed.  WRITE = true: stores the coefficients.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __restrict__ s, uint64_t total_bits,
+                                                            int nchunk, const DecTables* __restrict__ tabs,
+                                                            const ChunkState* __restrict__ entry,  // [nchunk]: exit of i - 1
+                                                            ChunkState* __restrict__ exit_state,    // [nchunk]
+                                                            uint64_t* __restrict__ nblocks, int* __restrict__ changed,
+                                                            const uint64_t* __restrict__ first_block, int64_t nblk,
+                                                            int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff) {
+  __shared__ DecTables t;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+    for (int i = threadIdx.x; i < (int)(sizeof(DecTables) / 4); i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunk) return;
+  const uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
+  ChunkState st = entry[i];
+  uint64_t p = st.p;
+  int k = st.k;
+  uint64_t blocks = 0;
+  int64_t b = WRITE ? (int64_t)first_block[i] : 0;
+  while (p < end) {
+    const uint64_t w = window(s, p);
+    int len;
+    if (k == 0) {
+      const int sz = decode_symbol(t.dc.look8, t.dc.maxcode, t.dc.valoff, t.dc.vals, w, len) & 15;
+      if (WRITE && b < nblk) {
+        int v = 0;
+        if (sz) {
+          v = (int)((w << len) >> (64 - sz));
+          if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+        }
+        dcdiff[b] = v;
+      }
+      p += (uint64_t)(len + sz);
+      k = 1;
+    } else {
+      const int rs = decode_symbol(t.ac.look8, t.ac.maxcode, t.ac.valoff, t.ac.vals, w, len);
+      const int r = rs >> 4, sz = rs & 15;
+      if (sz) {
+        k += r;
+        if (WRITE && b < nblk && k < 64) {
+          int v = (int)((w << len) >> (64 - sz));
+          if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+          // zig-zag position k of block b: [8 groups][block] x 8 int16 (the encoder's layout)
+          coef[((size_t)(k >> 3) * (size_t)nblk + (size_t)b) * 8 + (k & 7)] = (int16_t)v;
+        }
+        ++k;
+        p += (uint64_t)(len + sz);
+      } else if (r == 15) {
+        k += 16;
+        p += (uint64_t)len;
+      } else {  // end of block
+        k = 64;
+        p += (uint64_t)len;
+      }
+      if (k >= 64) {
+        k = 0;
+        ++blocks;
+        ++b;
+      }
+    }
+  }
+  if (!WRITE) {
+    const ChunkState old = exit_state[i];
+    if (old.p != p || old.k != k) *changed = 1;
+    ChunkState ns;
+    ns.p = p;
+    ns.k = k;
+    ns.pad = 0;
+    exit_state[i] = ns;
+    nblocks[i] = blocks;
+  }
+}
+
+// entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0)
+__global__ __launch_bounds__(256) void shift_states_kernel(const ChunkState* __restrict__ exit_state, int nchunk,
+                                                           ChunkState* __restrict__ entry) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunk) return;
+  if (i == 0) {
+    ChunkState z;
+    z.p = 0;
+    z.k = 0;
+    z.pad = 0;
+    entry[0] = z;
+  } else {
+    entry[i] = exit_state[i - 1];
+  }
+}
+
+__global__ __launch_bounds__(256) void init_states_kernel(int nchunk, ChunkState* __restrict__ entry,
+                                                          ChunkState* __restrict__ exit_state,
+                                                          uint64_t* __restrict__ nblocks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > nchunk) return;
+  if (i == nchunk) {
+    nblocks[i] = 0;  // sentinel of the scan
+    return;
+  }
+  ChunkState z;
+  z.p = (uint64_t)i * CHUNK_BITS;
+  z.k = 0;
+  z.pad = 0;
+  entry[i] = z;
+  z.p = ~0ull;
+  exit_state[i] = z;
+}
+
+// ---- D6 ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int range_limit(int x) {
+  // libjpeg's post-IDCT table, indexed with (x & 1023); x already includes the +128 level shift implicitly
+  const int i = x & 1023;
+  if (i < 128) return i + 128;
+  if (i < 512) return 255;
+  if (i < 896) return 0;
+  return i - 896;
+}
+
+template <int PASS>
+__device__ __forceinline__ void idct8(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr int SH = PASS == 1 ? CB - P1 : CB + P1 + 3;
+  constexpr int R = 1 << (SH - 1);
+  int z2 = d2, z3 = d6;
+  int z1 = (z2 + z3) * 4433;
+  const int tmp2 = z1 + z3 * (-15137);
+  const int tmp3 = z1 + z2 * 6270;
+  z2 = d0;
+  z3 = d4;
+  const int tmp0 = (z2 + z3) << CB, tmp1 = (z2 - z3) << CB;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  int t0 = d7, t1 = d5, t2 = d3, t3 = d1;
+  z1 = t0 + t3;
+  z2 = t1 + t2;
+  z3 = t0 + t2;
+  int z4 = t1 + t3;
+  const int z5 = (z3 + z4) * 9633;
+  t0 *= 2446;
+  t1 *= 16819;
+  t2 *= 25172;
+  t3 *= 12299;
+  z1 *= -7373;
+  z2 *= -20995;
+  z3 = z3 * (-16069) + z5;
+  z4 = z4 * (-3196) + z5;
+  t0 += z1 + z3;
+  t1 += z2 + z4;
+  t2 += z2 + z3;
+  t3 += z1 + z4;
+  d0 = (tmp10 + t3 + R) >> SH;
+  d7 = (tmp10 - t3 + R) >> SH;
+  d1 = (tmp11 + t2 + R) >> SH;
+  d6 = (tmp11 - t2 + R) >> SH;
+  d2 = (tmp12 + t1 + R) >> SH;
+  d5 = (tmp12 - t1 + R) >> SH;
+  d3 = (tmp13 + t0 + R) >> SH;
+  d4 = (tmp13 - t0 + R) >> SH;
+}
+
+__global__ __launch_bounds__(256) void idct_kernel(const uint4* __restrict__ coef, const int32_t* __restrict__ dc,
+                                                   const DecTables* __restrict__ tabs, int nbx, int nblk, int H, int W,
+                                                   uint8_t* __restrict__ img, ptrdiff_t stride) {
+  __shared__ int s_q[64];  // dequantisation factors in zig-zag order
+  constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  if (threadIdx.x < 64) s_q[threadIdx.x] = tabs->quant[ZZ[threadIdx.x]];
+  __syncthreads();
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nblk) return;
+  int d[64];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const uint4 v = coef[(size_t)g * nblk + b];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = g * 8 + j;
+      const int c = (int)(int16_t)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+      d[ZZ[k]] = (k == 0 ? dc[b] : c) * s_q[k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)  // pass 1: columns
+    idct8<1>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r)  // pass 2: rows
+    idct8<2>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+  const int by = b / nbx, bx = b - by * nbx;
+  const int x0 = bx * 8, y0 = by * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (y0 + r >= H) break;
+    uint8_t* row = img + (ptrdiff_t)(y0 + r) * stride + x0;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lo |= (uint32_t)range_limit(d[r * 8 + c]) << (8 * c);
+      hi |= (uint32_t)range_limit(d[r * 8 + 4 + c]) << (8 * c);
+    }
+    if (x0 + 8 <= W) {
+      typedef uint32_t u32u __attribute__((aligned(1)));
+      *reinterpret_cast<u32u*>(row) = lo;
+      *reinterpret_cast<u32u*>(row + 4) = hi;
+    } else {
+      for (int c = 0; c < 8 && x0 + c < W; ++c) row[c] = (uint8_t)((c < 4 ? lo >> (8 * c) : hi >> (8 * (c - 4))) & 255u);
+    }
+  }
+}
+
+// ---- host: file structure --------------------------------------------------------------------------------
+
+struct JpegInfo {
+  int H = 0, W = 0, ncomp = 0;
+  bool supported = false;
+  const char* why = "";
+  size_t scan_begin = 0, scan_end = 0;
+  DecTables tabs;
+};
+
+#define JP_UNSUP(msg)     \
+  do {                    \
+    info.why = msg;       \
+    return OGD_OK;        \
+  } while (0)
+
+// Parses the marker segments.  Returns OGD_ERR_INVALID for something that is not a JPEG file at all; a valid
+// file this decoder does not cover leaves info.supported = false with the reason in info.why.
+static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
+  OGD_REQUIRE(n >= 4 && f[0] == 0xFF && f[1] == 0xD8, "not a JPEG file (no SOI marker)");
+  uint8_t qt[4][64];
+  bool have_q[4] = {false, false, false, false};
+  struct RawHuff { uint8_t bits[16]; uint8_t vals[256]; int n = -1; } hd[4], ha[4];
+  int tq = -1, td = -1, ta = -1, comp_id = -1;
+  bool have_sof = false;
+  size_t p = 2;
+  while (true) {
+    OGD_REQUIRE(p + 4 <= n, "truncated JPEG file");
+    OGD_REQUIRE(f[p] == 0xFF, "JPEG marker expected at byte %zu", p);
+    while (p < n && f[p] == 0xFF) ++p;  // fill bytes
+    OGD_REQUIRE(p < n, "truncated JPEG file");
+    const int m = f[p++];
+    if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    OGD_REQUIRE(m != 0xD9, "JPEG file ends before the scan");
+    OGD_REQUIRE(p + 2 <= n, "truncated JPEG file");
+    const size_t len = ((size_t)f[p] << 8) | f[p + 1];
+    OGD_REQUIRE(len >= 2 && p + len <= n, "bad JPEG segment length");
+    const uint8_t* s = f + p + 2;
+    const size_t sl = len - 2;
+    if (m == 0xDB) {
+      size_t o = 0;
+      while (o < sl) {
+        const int pq = s[o] >> 4, id = s[o] & 15;
+        OGD_REQUIRE(id < 4, "bad quantisation table id");
+        if (pq != 0) JP_UNSUP("16-bit quantisation table");
+        OGD_REQUIRE(o + 65 <= sl, "truncated DQT segment");
+        static const uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        for (int k = 0; k < 64; ++k) qt[id][ZZ[k]] = s[o + 1 + k];
+        have_q[id] = true;
+        o += 65;
+      }
+    } else if (m == 0xC4) {
+      size_t o = 0;
+      while (o < sl) {
+        OGD_REQUIRE(o + 17 <= sl, "truncated DHT segment");
+        const int tc = s[o] >> 4, id = s[o] & 15;
+        OGD_REQUIRE(tc < 2 && id < 4, "bad Huffman table id");
+        RawHuff& h = tc ? ha[id] : hd[id];
+        int cnt = 0;
+        for (int k = 0; k < 16; ++k) cnt += (h.bits[k] = s[o + 1 + k]);
+        OGD_REQUIRE(cnt <= 256 && o + 17 + (size_t)cnt <= sl, "bad DHT segment");
+        std::memcpy(h.vals, s + o + 17, (size_t)cnt);
+        h.n = cnt;
+        o += 17 + (size_t)cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      OGD_REQUIRE(sl >= 6, "truncated SOF segment");
+      info.H = (s[1] << 8) | s[2];
+      info.W = (s[3] << 8) | s[4];
+      info.ncomp = s[5];
+      have_sof = true;
+      if (s[0] != 8) JP_UNSUP("sample precision other than 8 bits");
+      if (info.ncomp != 1) JP_UNSUP("more than one component");
+      OGD_REQUIRE(sl >= 9, "truncated SOF segment");
+      comp_id = s[6];
+      tq = s[8];
+      OGD_REQUIRE(tq < 4, "bad quantisation table selector");
+      if (info.H == 0 || info.W == 0) JP_UNSUP("image height defined by a DNL marker");
+    } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      if (sl >= 6) {
+        info.H = (s[1] << 8) | s[2];
+        info.W = (s[3] << 8) | s[4];
+        info.ncomp = s[5];
+      }
+      JP_UNSUP("not a baseline / sequential Huffman file");
+    } else if (m == 0xDD) {
+      OGD_REQUIRE(sl >= 2, "truncated DRI segment");
+      if (((s[0] << 8) | s[1]) != 0) JP_UNSUP("restart intervals");
+    } else if (m == 0xDA) {
+      OGD_REQUIRE(have_sof, "SOS before SOF");
+      OGD_REQUIRE(sl >= 6 && s[0] == 1 && s[1] == comp_id, "bad SOS segment");
+      td = s[2] >> 4;
+      ta = s[2] & 15;
+      OGD_REQUIRE(td < 4 && ta < 4, "bad Huffman table selector");
+      if (s[3] != 0 || s[4] != 63 || s[5] != 0) JP_UNSUP("spectral selection / successive approximation");
+      p += len;
+      break;
+    }
+    p += len;
+  }
+  OGD_REQUIRE(have_q[tq] && hd[td].n >= 0 && ha[ta].n >= 0, "JPEG scan refers to a table that was not defined");
+  // the entropy-coded segment ends at the first marker that is not stuffing
+  size_t e = p;
+  while (true) {
+    const uint8_t* ff = (const uint8_t*)std::memchr(f + e, 0xFF, n - e);
+    OGD_REQUIRE(ff && (size_t)(ff - f) + 1 < n, "JPEG scan is not terminated by a marker");
+    e = (size_t)(ff - f);
+    if (f[e + 1] == 0x00) {
+      e += 2;
+      continue;
+    }
+    break;
+  }
+  if (f[e + 1] != 0xD9) JP_UNSUP("marker inside the scan");  // RSTn, further scans, fill bytes
+  info.scan_begin = p;
+  info.scan_end = e;
+  for (int k = 0; k < 64; ++k) info.tabs.quant[k] = qt[tq][k];
+  OGD_REQUIRE(build_dec_huff(hd[td].bits, hd[td].vals, hd[td].n, info.tabs.dc) &&
+                  build_dec_huff(ha[ta].bits, ha[ta].vals, ha[ta].n, info.tabs.ac),
+              "inconsistent Huffman table");
+  info.supported = true;
+  return OGD_OK;
+}
+
+static int scan_u64(DevBuf& tmp, uint64_t* d, int count, hipStream_t st) {
+  size_t bytes = 0;
+  OGD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d, d, count, st));
+  OGD_TRY(tmp.alloc(bytes));
+  OGD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, d, d, count, st));
+  return OGD_OK;
+}
+
+static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride, hipStream_t st) {
+  const int H = info.H, W = info.W;
+  const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
+  const int64_t nblk = (int64_t)nbx * nby;
+  OGD_REQUIRE(nblk < INT_MAX - 256, "too many blocks");
+  const uint64_t nscan = info.scan_end - info.scan_begin;
+  OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
+
+  // D1
+  const int64_t nun64 = (int64_t)((nscan + UN_CHUNK - 1) / UN_CHUNK);
+  OGD_REQUIRE(nun64 < INT_MAX - 1, "JPEG scan too long");
+  const int nun = (int)nun64;
+  DevBuf draw, dcnt, dtmp1, dstream, dtabs;
+  OGD_TRY(draw.alloc((size_t)nscan + 16));
+  OGD_TRY(dcnt.alloc(((size_t)nun + 1) * sizeof(uint64_t)));
+  OGD_TRY(dstream.alloc((size_t)nscan + 64));
+  OGD_TRY(dtabs.alloc(sizeof(DecTables)));
+  OGD_HIP(hipMemcpyAsync(draw.p, file + info.scan_begin, (size_t)nscan, hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemcpyAsync(dtabs.p, &info.tabs, sizeof(DecTables), hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemsetAsync(dstream.p, 0, (size_t)nscan + 64, st));
+  hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)nun + 1), dim3(256), 0, st, draw.as<uint8_t>(), nscan, nun,
+                     dcnt.as<uint64_t>());
+  OGD_TRY(check_launch("unstuff_count_kernel"));
+  OGD_TRY(scan_u64(dtmp1, dcnt.as<uint64_t>(), nun + 1, st));
+  hipLaunchKernelGGL(unstuff_compact_kernel, dim3((unsigned)nun), dim3(256), 0, st, draw.as<uint8_t>(), nscan,
+                     dcnt.as<uint64_t>(), dstream.as<uint8_t>());
+  OGD_TRY(check_launch("unstuff_compact_kernel"));
+  uint64_t removed = 0;
+  OGD_HIP(hipMemcpyAsync(&removed, dcnt.as<uint64_t>() + nun, sizeof removed, hipMemcpyDeviceToHost, st));
+  OGD_HIP(hipStreamSynchronize(st));
+  const uint64_t total_bits = (nscan - removed) * 8;
+
+  // D2
+  const int64_t nchunk64 = (int64_t)((total_bits + CHUNK_BITS - 1) / CHUNK_BITS);
+  OGD_REQUIRE(nchunk64 >= 1 && nchunk64 < INT_MAX - 256, "JPEG scan too long");
+  const int nchunk = (int)nchunk64;
+  DevBuf dentry, dexit, dnb, dflag, dtmp2;
+  OGD_TRY(dentry.alloc((size_t)nchunk * sizeof(ChunkState)));
+  OGD_TRY(dexit.alloc((size_t)nchunk * sizeof(ChunkState)));
+  OGD_TRY(dnb.alloc(((size_t)nchunk + 1) * sizeof(uint64_t)));
+  OGD_TRY(dflag.alloc(16));
+  const dim3 cgrid((unsigned)((nchunk + 255) / 256)), cgrid1((unsigned)((nchunk + 1 + 255) / 256)), blk(256);
+  hipLaunchKernelGGL(init_states_kernel, cgrid1, blk, 0, st, nchunk, dentry.as<ChunkState>(), dexit.as<ChunkState>(),
+                     dnb.as<uint64_t>());
+  OGD_TRY(check_launch("init_states_kernel"));
+  const DecTables* tabs = dtabs.as<DecTables>();
+  int rounds = 0;
+  while (true) {
+    OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
+    hipLaunchKernelGGL(decode_chunks_kernel<false>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
+                       dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
+                       (const uint64_t*)nullptr, (int64_t)0, (int16_t*)nullptr, (int32_t*)nullptr);
+    OGD_TRY(check_launch("decode_chunks_kernel"));
+    int changed = 0;
+    OGD_HIP(hipMemcpyAsync(&changed, dflag.p, sizeof changed, hipMemcpyDeviceToHost, st));
+    OGD_HIP(hipStreamSynchronize(st));
+    ++rounds;
+    if (!changed) break;
+    OGD_REQUIRE(rounds <= nchunk + 1, "JPEG chunk states did not settle");  // cannot happen: chunk r is exact after round r
+    hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>());
+    OGD_TRY(check_launch("shift_states_kernel"));
+  }
+  // the last round ran from entry = shifted exits of the round before and reproduced them: entry is exact
+
+  // D3
+  OGD_TRY(scan_u64(dtmp2, dnb.as<uint64_t>(), nchunk + 1, st));
+  uint64_t blocks_found = 0;
+  OGD_HIP(hipMemcpyAsync(&blocks_found, dnb.as<uint64_t>() + nchunk, sizeof blocks_found, hipMemcpyDeviceToHost, st));
+  OGD_HIP(hipStreamSynchronize(st));
+  if (blocks_found < (uint64_t)nblk)
+    return fail(OGD_ERR_RUNTIME, "JPEG scan holds %llu blocks, the image needs %lld", (unsigned long long)blocks_found,
+                (long long)nblk);
+
+  // D4, D5, D6
+  DevBuf dcoef, ddc, dtmp3;
+  OGD_TRY(dcoef.alloc((size_t)nblk * 64 * sizeof(int16_t)));
+  OGD_TRY(ddc.alloc((size_t)nblk * sizeof(int32_t)));
+  OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
+  hipLaunchKernelGGL(decode_chunks_kernel<true>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
+                     dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
+                     dnb.as<uint64_t>(), nblk, dcoef.as<int16_t>(), ddc.as<int32_t>());
+  OGD_TRY(check_launch("decode_chunks_kernel<write>"));
+  size_t sb = 0;
+  OGD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));
+  OGD_TRY(dtmp3.alloc(sb));
+  OGD_HIP(hipcub::DeviceScan::InclusiveSum(dtmp3.p, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));
+  hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), blk, 0, st, dcoef.as<uint4>(), ddc.as<int32_t>(),
+                     tabs, nbx, (int)nblk, H, W, d_img, stride);
+  OGD_TRY(check_launch("idct_kernel"));
+  OGD_HIP(hipStreamSynchronize(st));  // the scratch buffers go back to the block cache on return
+  return OGD_OK;
+}
+
+}  // namespace
+}  // namespace ogd
+
+using namespace ogd;
+
+extern "C" {
+
+int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* supported) {
+  OGD_REQUIRE(file && H && W && ncomp && supported, "null pointer");
+  JpegInfo info;
+  OGD_TRY(parse_jpeg(file, n, info));
+  *H = info.H;
+  *W = info.W;
+  *ncomp = info.ncomp;
+  *supported = info.supported ? 1 : 0;
+  if (!info.supported) set_error("JPEG decoder: %s", info.why);
+  return OGD_OK;
+}
+
+int ogd_jpeg_decode_gray(const uint8_t* file, size_t n, uint8_t* out, int H, int W, ptrdiff_t stride) {
+  OGD_REQUIRE(file && out, "null pointer");
+  JpegInfo info;
+  OGD_TRY(parse_jpeg(file, n, info));
+  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
+  OGD_REQUIRE(H == info.H && W == info.W, "output is %dx%d, the file holds %dx%d", W, H, info.W, info.H);
+  OGD_REQUIRE(stride >= W, "row stride %td < %d bytes", stride, W);
+  OGD_TRY(ensure_device());
+  DevBuf dimg;
+  OGD_TRY(dimg.alloc((size_t)H * W));
+  OGD_TRY(decode_to_device(file, info, dimg.as<uint8_t>(), W, nullptr));
+  OGD_HIP(copy_rows(out, (size_t)stride, dimg.p, (size_t)W, (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_jpeg_decode_gray_dev(const uint8_t* file, size_t n, uint8_t* d_out, int H, int W, ptrdiff_t stride, void* stream) {
+  OGD_REQUIRE(file && d_out, "null pointer");
+  JpegInfo info;
+  OGD_TRY(parse_jpeg(file, n, info));
+  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
+  OGD_REQUIRE(H == info.H && W == info.W, "output is %dx%d, the file holds %dx%d", W, H, info.W, info.H);
+  OGD_REQUIRE(stride >= W, "row stride %td < %d bytes", stride, W);
+  OGD_TRY(ensure_device());
+  return decode_to_device(file, info, d_out, stride, as_stream(stream));
+}
+
+}  // extern "C"

@@ -50,9 +50,19 @@ class Page:
 	@property
 	def warped(self):
 		if self._warped is None:
-			self._warped = self._opened.convert("L")
+			self._warped = self._decode_on_device() or self._opened.convert("L")
 			self._opened = None
 		return self._warped
+
+	def _decode_on_device(self):
+		"""A baseline grayscale JPEG scan is decoded by ogd_jpeg_decode_gray: the pixels PIL would give, bit for
+		bit, in a few ms instead of 0.15 s.  Any other file (PNG, colour or progressive JPEG, JPEG 2000 ...)
+		returns None and goes through PIL as in the reference (ref: page.py:82-84)."""
+		if self._opened.format != "JPEG" or self._opened.mode != "L" or not getattr(self._opened, "filename", None):
+			return None
+		data = Path(self._opened.filename).read_bytes()
+		pixels = _shim.jpeg_decode_gray(data)
+		return None if pixels is None else PIL.Image.fromarray(pixels)
 
 	@property
 	def dewarped(self):

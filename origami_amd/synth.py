@@ -116,10 +116,10 @@ def polygon_rings(rng, size, n, mu=48.0, sigma=0.6, lo=4, hi=400, integer_scale=
 
 
 def write_page_dir(root, name, rng, size=(2400, 3400), n_h=300, n_v=500, n_regions=60,
-		n_separators=12, warp=None, label_size=(1280, 2400)):
-	"""Writes `<root>/<name>.png` and the `<name>.out/` inputs of the dewarp stage
-	(SURVEY.md Appendix B): segment.zip, contours.0.zip, flow.zip."""
-	page_path = root / ("%s.png" % name)
+		n_separators=12, warp=None, label_size=(1280, 2400), suffix=".png"):
+	"""Writes `<root>/<name>.png` (or `.jpg`: the reference's usual page format) and the `<name>.out/` inputs
+	of the dewarp stage: segment.zip, contours.0.zip, flow.zip."""
+	page_path = root / (name + suffix)
 	PIL.Image.fromarray(text_page(rng, size)).save(page_path)
 	write_page_inputs(page_path, rng, size, n_h, n_v, n_regions, n_separators, warp, label_size)
 	return page_path

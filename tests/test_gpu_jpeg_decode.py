@@ -1,0 +1,84 @@
+"""N4: the device-side baseline JPEG decoder (ogd_jpeg_decode_gray) against PIL / libjpeg-turbo, which is what
+the reference's `PIL.Image.open(path).convert("L")` runs (ref: origami/core/page.py:82-84).  Bar: the same
+pixels, bit for bit.  The files are made here with PIL's encoder (and with the device encoder)."""
+
+import io
+
+import numpy as np
+import PIL.Image
+import pytest
+
+from oracle import jpeg as ojpeg
+from origami_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pil_decode(data):
+	return np.array(PIL.Image.open(io.BytesIO(data)).convert("L"))
+
+
+def _check(gpu, pixels, **params):
+	data = ojpeg.save_gray(pixels, **params)
+	got = gpu.jpeg_decode_gray(data)
+	assert got is not None, "decoder refused a baseline grayscale file"
+	want = _pil_decode(data)
+	assert got.shape == want.shape
+	assert np.array_equal(got, want), "%d pixels differ, max %d" % (
+		(got != want).sum(), np.abs(got.astype(int) - want).max())
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 9), (8, 8), (17, 33), (64, 64), (250, 301), (1000, 777)])
+def test_noise_images_of_ragged_sizes(gpu, shape):
+	rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+	_check(gpu, rng.integers(0, 256, size=shape, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("quality", [1, 10, 50, 75, 90, 95, 100])
+def test_qualities(gpu, quality):
+	rng = np.random.default_rng(quality)
+	_check(gpu, synth.text_page(rng, (640, 480)), quality=quality)
+	_check(gpu, rng.integers(0, 256, size=(96, 200), dtype=np.uint8), quality=quality)
+
+
+def test_optimised_huffman_tables(gpu):
+	"""optimize=True: tables fitted to the image (codes of up to 16 bits, not the standard ones)."""
+	rng = np.random.default_rng(3)
+	_check(gpu, synth.text_page(rng, (800, 600)), optimize=True)
+	_check(gpu, rng.integers(0, 256, size=(200, 200), dtype=np.uint8), optimize=True, quality=95)
+
+
+def test_flat_and_extreme_images(gpu):
+	_check(gpu, np.zeros((40, 40), np.uint8))
+	_check(gpu, np.full((2000, 40), 255, np.uint8))  # long runs of identical blocks: chunks without a block start
+	yy, xx = np.mgrid[0:200, 0:312]
+	for period in (1, 3, 8):
+		_check(gpu, (((yy // period + xx // period) & 1) * 255).astype(np.uint8), quality=100)
+
+
+def test_files_outside_the_domain_are_refused_not_misdecoded(gpu):
+	rng = np.random.default_rng(4)
+	rgb = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rgb).save(buf, format="JPEG")
+	assert gpu.jpeg_info(buf.getvalue())[2:] == (3, False)
+	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rgb[:, :, 0]).save(buf, format="JPEG", progressive=True)
+	assert gpu.jpeg_info(buf.getvalue())[3] is False
+	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
+	with pytest.raises(gpu.OgdError):
+		gpu.jpeg_info(b"not a jpeg file at all")
+
+
+def test_decodes_what_the_device_encoder_wrote(gpu):
+	rng = np.random.default_rng(5)
+	page = synth.text_page(rng, (900, 700))
+	data = gpu.jpeg_encode_gray(page, quality=85)
+	assert np.array_equal(gpu.jpeg_decode_gray(data), _pil_decode(data))
+
+
+def test_whole_broadsheet_scan(gpu):
+	"""configs[1] size: a 6000 x 8000 scan."""
+	rng = np.random.default_rng(7)
+	_check(gpu, synth.text_page(rng, (6000, 8000)))

@@ -227,3 +227,30 @@ def test_dewarped_image_stage_matches_oracle(gpu, tmp_path):
 	# done pages are skipped on a second run (output exists), redone with --overwrite
 	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
 	assert res.exit_code == 0
+
+
+def test_dewarped_image_stage_on_a_jpeg_scan(gpu, tmp_path):
+	"""The reference's usual page format: a grayscale .jpg scan.  The page is decoded on the device
+	(ogd_jpeg_decode_gray, ref: origami/core/page.py:82-84), dewarped and encoded there; the result is the file
+	PIL writes for the oracle's dewarp of the PIL-decoded scan."""
+	import PIL.Image
+	from oracle import dewarp as odw2
+	from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
+	from origami_amd.page import Page
+	rng = np.random.default_rng(32)
+	size = (648, 470)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=100, n_v=120, n_regions=8, n_separators=2, label_size=(324, 235),
+		suffix=".jpg")
+	assert PIL.Image.open(page_path).mode == "L"
+	pixels = np.array(PIL.Image.open(page_path).convert("L"))
+	assert np.array_equal(np.array(Page(page_path).warped), pixels)  # device decode == PIL decode
+	out = page_path.with_suffix(".out")
+	assert CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"]).exit_code == 0
+	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	nodes = Grid.open(out / "dewarp.zip").points("sample")
+	want = PIL.Image.fromarray(odw2.dewarped(pixels, odw2.Grid(nodes, 25)))
+	ref = io.BytesIO()
+	want.save(ref, format="JPEG")
+	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()

@@ -70,3 +70,23 @@ print("ogd_dewarp_jpeg_gray (page in, file out):  %8.1f ms" % (dt * 1e3))
 dt2, _ = timed(lambda: ojpeg.save_gray(_shim.dewarp_u8(page, nodes, s)))
 print("ogd_dewarp_u8 + PIL save (before):         %8.1f ms" % (dt2 * 1e3))
 print("all outputs byte-identical to PIL's file")
+
+# ---- decoding the scan (ref: origami/core/page.py:82-84) ----
+import io
+import PIL.Image
+scan = ojpeg.save_gray(page)
+t0 = time.perf_counter()
+want_px = np.array(PIL.Image.open(io.BytesIO(scan)).convert("L"))
+t_pil = time.perf_counter() - t0
+print("scan %dx%d as a JPEG file of %d bytes" % (W, H, len(scan)))
+print("PIL / libjpeg-turbo decode, 1 host thread:  %8.1f ms = %7.0f MP/s" % (t_pil * 1e3, H * W / 1e6 / t_pil))
+dt, got_px = timed(lambda: _shim.jpeg_decode_gray(scan))
+assert np.array_equal(got_px, want_px)
+print("ogd_jpeg_decode_gray (file in, host pixels): %7.1f ms = %7.0f MP/s" % (dt * 1e3, H * W / 1e6 / dt))
+buf = np.frombuffer(scan, np.uint8)
+d_px = ctypes.c_void_p()
+_shim.check(lib.ogd_dev_alloc(ctypes.byref(d_px), H * W))
+dt, _ = timed(lambda: _shim.check(lib.ogd_jpeg_decode_gray_dev(buf.ctypes.data, buf.size, d_px, H, W, W, None)))
+print("ogd_jpeg_decode_gray_dev (pixels stay on the device): %5.1f ms = %7.0f MP/s" % (dt * 1e3, H * W / 1e6 / dt))
+_shim.check(lib.ogd_dev_free(d_px))
+print("decoded pixels identical to PIL's")

@@ -68,6 +68,23 @@ def main():
 		t_dec = time.perf_counter() - t
 		print("utils.dewarp stage (page PNG -> annotation.dewarped.jpg): %.3f s = %.1f ms/page, of which PIL decodes the page for %.1f ms" % (
 			dt, 1e3 * dt / n_pages, 1e3 * t_dec))
+		# the same pages as grayscale JPEG scans: decoded on the device (ogd_jpeg_decode_gray)
+		im = PIL.Image.open(first).convert("L")
+		for k in range(n_pages):
+			png = root / ("page%04d.png" % k)
+			im.save(png.with_suffix(".jpg"), quality=90)
+			png.unlink()
+		run_image_stage()
+		dt = run_image_stage()
+		t = time.perf_counter()
+		PIL.Image.open(root / "page0000.jpg").convert("L").load()
+		t_dec = time.perf_counter() - t
+		print("utils.dewarp stage (page JPG -> annotation.dewarped.jpg): %.3f s = %.1f ms/page (PIL would decode such a page in %.1f ms)" % (
+			dt, 1e3 * dt / n_pages, 1e3 * t_dec))
+		for k in range(n_pages):  # back to PNG pages for the profile below
+			jpg = root / ("page%04d.jpg" % k)
+			im.save(jpg.with_suffix(".png"), compress_level=1)
+			jpg.unlink()
 		if not workers:
 			pr = cProfile.Profile()
 			pr.enable()
