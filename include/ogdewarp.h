@@ -124,6 +124,10 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
  * outside the decoder's domain, OGD_ERR_RUNTIME for a scan with too few blocks.  _dev: output in device memory.
  */
 int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* supported);
+/* scan file in -> dewarped page's file out (decode, ogd_dewarp_u8 with C = 1, scale 1, linear, encode: the
+ * whole `utils.dewarp` step; only the two files cross PCIe).  OGD_ERR_UNSUPPORTED as ogd_jpeg_decode_gray. */
+int ogd_jpeg_dewarp_jpeg_gray(const uint8_t* file, size_t n, const float* nodes, int h, int w, int s,
+                              int quality, uint8_t* out, size_t cap, size_t* out_size);
 int ogd_jpeg_decode_gray(const uint8_t* file, size_t n, uint8_t* out, int H, int W, ptrdiff_t stride);
 int ogd_jpeg_decode_gray_dev(const uint8_t* file, size_t n, uint8_t* d_out, int H, int W, ptrdiff_t stride,
                              void* stream);

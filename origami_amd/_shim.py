@@ -98,6 +98,8 @@ SIGNATURES = {
 		c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
 		POINTER(c_size_t)]),
 	"ogd_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+	"ogd_jpeg_dewarp_jpeg_gray": (c_int, [
+		c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
 	"ogd_jpeg_decode_gray": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t]),
 	"ogd_jpeg_decode_gray_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t, c_void_p]),
 	"ogd_line_label_counts": (c_int, [
@@ -284,6 +286,26 @@ def dewarp_jpeg_gray(src, nodes, cell, quality=75):
 		h * cell * w * cell)
 
 
+def jpeg_dewarp_jpeg_gray(data, nodes, cell, quality=75):
+	"""Scan file -> dewarped page's JPEG file, all on the device; None if the scan is outside the decoder's domain."""
+	buf = np.frombuffer(data, dtype=np.uint8)
+	H, W, nc, ok = jpeg_info(data)
+	if not ok:
+		return None
+	nodes = _c(nodes, np.float32)
+	h, w = nodes.shape[:2]
+	lib = load()
+	try:
+		return _jpeg_call(
+			lambda out, cap, size: lib.ogd_jpeg_dewarp_jpeg_gray(
+				_ptr(buf), buf.size, _ptr(nodes), h, w, int(cell), int(quality), out, cap, size),
+			h * cell * w * cell)
+	except OgdError as e:
+		if e.status in (ERR_UNSUPPORTED, ERR_RUNTIME):
+			return None
+		raise
+
+
 def jpeg_info(data):
 	"""(H, W, components, supported) of a JPEG file held in `data` (bytes)."""
 	buf = np.frombuffer(data, dtype=np.uint8)
@@ -301,7 +323,7 @@ def jpeg_decode_gray(data):
 		return None
 	out = np.empty((H, W), dtype=np.uint8)
 	status = load().ogd_jpeg_decode_gray(_ptr(buf), buf.size, _ptr(out), H, W, out.strides[0])
-	if status == ERR_UNSUPPORTED:
+	if status in (ERR_UNSUPPORTED, ERR_RUNTIME):  # ERR_RUNTIME: truncated scan — PIL decides what to make of it
 		return None
 	check(status)
 	return out
@@ -387,6 +409,7 @@ class DevicePage:
 # ---- N3: lattice Delaunay (host) --------------------------------------------------------------------
 
 ERR_UNSUPPORTED = -5
+ERR_RUNTIME = -6
 
 
 def lattice_delaunay(points_hw2):

@@ -58,7 +58,7 @@ class Page:
 		"""A baseline grayscale JPEG scan is decoded by ogd_jpeg_decode_gray: the pixels PIL would give, bit for
 		bit, in a few ms instead of 0.15 s.  Any other file (PNG, colour or progressive JPEG, JPEG 2000 ...)
 		returns None and goes through PIL as in the reference (ref: page.py:82-84)."""
-		if self._opened.format != "JPEG" or self._opened.mode != "L" or not getattr(self._opened, "filename", None):
+		if not self._on_device_format():
 			return None
 		data = Path(self._opened.filename).read_bytes()
 		pixels = _shim.jpeg_decode_gray(data)
@@ -69,8 +69,21 @@ class Page:
 		return self.dewarper.dewarped if self._grid is not None else None
 
 	def dewarped_jpeg(self, quality=75):
-		"""`self.dewarped` as the JPEG file PIL would save (bytes), encoded on the device."""
-		return self.dewarper.dewarped_jpeg(quality) if self._grid is not None else None
+		"""`self.dewarped` as the JPEG file PIL would save (bytes), encoded on the device.  For a page that is
+		still an undecoded grayscale JPEG scan, decode, dewarp and encoding run back to back on the device
+		(ogd_jpeg_dewarp_jpeg_gray): only the two files cross PCIe."""
+		if self._grid is None:
+			return None
+		if self._warped is None and self._on_device_format():
+			data = Path(self._opened.filename).read_bytes()
+			out = _shim.jpeg_dewarp_jpeg_gray(data, self._grid.points("sample"), self._grid.resolution, quality)
+			if out is not None:
+				return out
+		return self.dewarper.dewarped_jpeg(quality)
+
+	def _on_device_format(self):
+		return (self._opened is not None and self._opened.format == "JPEG" and self._opened.mode == "L"
+			and bool(getattr(self._opened, "filename", None)))
 
 	def size(self, dewarped):
 		if dewarped:

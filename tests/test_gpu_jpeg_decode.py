@@ -71,6 +71,13 @@ def test_files_outside_the_domain_are_refused_not_misdecoded(gpu):
 		gpu.jpeg_info(b"not a jpeg file at all")
 
 
+def test_truncated_scan_is_left_to_pil(gpu):
+	rng = np.random.default_rng(9)
+	data = ojpeg.save_gray(synth.text_page(rng, (400, 300)))
+	cut = data[:len(data) // 2] + b"\xff\xd9"  # half the scan, then EOI
+	assert gpu.jpeg_decode_gray(cut) is None
+
+
 def test_decodes_what_the_device_encoder_wrote(gpu):
 	rng = np.random.default_rng(5)
 	page = synth.text_page(rng, (900, 700))
@@ -82,3 +89,17 @@ def test_whole_broadsheet_scan(gpu):
 	"""configs[1] size: a 6000 x 8000 scan."""
 	rng = np.random.default_rng(7)
 	_check(gpu, synth.text_page(rng, (6000, 8000)))
+
+
+def test_scan_file_to_dewarped_file_on_the_device(gpu):
+	"""ogd_jpeg_dewarp_jpeg_gray = decode, dewarp, encode without leaving the device: the file PIL writes for the
+	oracle-checked dewarp of the PIL-decoded scan."""
+	rng = np.random.default_rng(10)
+	size = (1100, 1500)
+	scan = ojpeg.save_gray(synth.text_page(rng, size), quality=88)
+	nodes = synth.Warp.random(rng, size).node_grid(25)
+	want = ojpeg.save_gray(gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
+	assert gpu.jpeg_dewarp_jpeg_gray(scan, nodes, 25) == want
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(buf, format="JPEG")
+	assert gpu.jpeg_dewarp_jpeg_gray(buf.getvalue(), nodes, 25) is None
