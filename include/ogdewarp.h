@@ -189,6 +189,9 @@ int ogd_grid_sample_bilinear(const float* nodes, int h, int w, int s,
  * are extracted by ONE launch. */
 typedef struct ogd_page ogd_page;
 int ogd_page_create(const uint8_t* src, int H, int W, int C, ptrdiff_t src_stride, ogd_page** out);
+/* The page of a grayscale baseline JPEG scan, decoded straight into device memory (ogd_jpeg_decode_gray_dev);
+ * OGD_ERR_UNSUPPORTED for other files: decode on the host and use ogd_page_create. */
+int ogd_page_create_jpeg(const uint8_t* file, size_t n, ogd_page** out);
 int ogd_page_destroy(ogd_page* page);
 /* Dewarper.dewarped / dewarp_image of a resident page (fused K1a + K2), ref: dewarp.py:608-627. */
 int ogd_page_dewarp_u8(const ogd_page* page, const float* nodes, int h, int w, int s, float sx, float sy,

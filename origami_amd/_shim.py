@@ -100,6 +100,7 @@ SIGNATURES = {
 	"ogd_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 	"ogd_jpeg_dewarp_jpeg_gray": (c_int, [
 		c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
+	"ogd_page_create_jpeg": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
 	"ogd_jpeg_decode_gray": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t]),
 	"ogd_jpeg_decode_gray_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_int, c_ssize_t, c_void_p]),
 	"ogd_line_label_counts": (c_int, [
@@ -342,8 +343,27 @@ class DevicePage:
 			_ptr(src), src.shape[0], src.shape[1], src.shape[2], src.strides[0], ctypes.byref(h)))
 		self._h = h
 
+	@classmethod
+	def from_jpeg(cls, data):
+		"""The page of a grayscale baseline JPEG scan, decoded straight into device memory; None for any other
+		file (decode it on the host and use DevicePage(pixels))."""
+		H, W, nc, ok = jpeg_info(data)
+		if not ok:
+			return None
+		buf = np.frombuffer(data, dtype=np.uint8)
+		h = c_void_p()
+		status = load().ogd_page_create_jpeg(_ptr(buf), buf.size, ctypes.byref(h))
+		if status in (ERR_UNSUPPORTED, ERR_RUNTIME):
+			return None
+		check(status)
+		self = cls.__new__(cls)
+		self._squeeze = True
+		self.shape = (H, W, 1)
+		self._h = h
+		return self
+
 	def close(self):
-		if self._h is not None and _lib is not None:
+		if getattr(self, "_h", None) is not None and _lib is not None:
 			_lib.ogd_page_destroy(self._h)
 		self._h = None
 

@@ -124,6 +124,35 @@ int ogd_page_create(const uint8_t* src, int H, int W, int C, ptrdiff_t src_strid
   return OGD_OK;
 }
 
+int ogd_page_create_jpeg(const uint8_t* file, size_t n, ogd_page** out) {
+  OGD_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  OGD_REQUIRE(file != nullptr, "null pointer");
+  int H = 0, W = 0, ncomp = 0, supported = 0;
+  OGD_TRY(ogd_jpeg_info(file, n, &H, &W, &ncomp, &supported));
+  if (!supported) return OGD_ERR_UNSUPPORTED;  // ogd_last_error() already names the reason
+  OGD_REQUIRE(H < 32768 && W < 32768, "page %dx%d not supported", W, H);
+  OGD_TRY(ensure_device());
+  ogd_page* p = new (std::nothrow) ogd_page();
+  if (!p) return fail(OGD_ERR_NOMEM, "out of host memory");
+  (void)hipGetDevice(&p->device);
+  p->H = H; p->W = W; p->C = 1;
+  p->stride = (ptrdiff_t)W;
+  hipError_t e = hipMalloc((void**)&p->d, (size_t)W * H);
+  if (e != hipSuccess) {
+    delete p;
+    return fail(OGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)W * H, hipGetErrorString(e));
+  }
+  const int st = ogd_jpeg_decode_gray_dev(file, n, p->d, H, W, W, nullptr);
+  if (st != OGD_OK) {
+    (void)hipFree(p->d);
+    delete p;
+    return st;
+  }
+  *out = p;
+  return OGD_OK;
+}
+
 int ogd_page_destroy(ogd_page* p) {
   if (!p) return OGD_OK;
   int prev = -1;

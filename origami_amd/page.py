@@ -106,5 +106,8 @@ class Page:
 	def device_page(self):
 		"""The warped page resident in device memory; line images are cut from it (block.py:255)."""
 		if self._device_page is None:
-			self._device_page = _shim.DevicePage(np.array(self.warped))
+			if self._warped is None and self._on_device_format():  # an undecoded JPEG scan never visits the host
+				self._device_page = _shim.DevicePage.from_jpeg(Path(self._opened.filename).read_bytes())
+			if self._device_page is None:
+				self._device_page = _shim.DevicePage(np.array(self.warped))
 		return self._device_page

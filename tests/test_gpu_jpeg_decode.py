@@ -103,3 +103,16 @@ def test_scan_file_to_dewarped_file_on_the_device(gpu):
 	buf = io.BytesIO()
 	PIL.Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(buf, format="JPEG")
 	assert gpu.jpeg_dewarp_jpeg_gray(buf.getvalue(), nodes, 25) is None
+
+
+def test_resident_page_from_a_scan_file(gpu):
+	"""ogd_page_create_jpeg: the page decoded into device memory dewarps like the PIL-decoded one."""
+	rng = np.random.default_rng(11)
+	size = (900, 1200)
+	scan = ojpeg.save_gray(synth.text_page(rng, size), quality=92)
+	nodes = synth.Warp.random(rng, size).node_grid(25)
+	with gpu.DevicePage.from_jpeg(scan) as page:
+		assert page.shape == (1200, 900, 1)
+		got = page.dewarp(nodes, 25)
+	assert np.array_equal(got, gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
+	assert gpu.DevicePage.from_jpeg(ojpeg.save_gray(np.zeros((16, 16), np.uint8), progressive=True)) is None
