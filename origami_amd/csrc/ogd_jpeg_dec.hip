@@ -22,6 +22,7 @@
 //   D5 inclusive scan of the DC differences (hipCUB), D6 idct_kernel: thread per 8x8 block
 #include "ogd_common.h"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
                                                             ChunkState* __restrict__ exit_state,    // [nchunk]
                                                             uint64_t* __restrict__ nblocks, int* __restrict__ changed,
                                                             const uint64_t* __restrict__ first_block, int64_t nblk,
-                                                            int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff) {
+                                                            int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff,
+                                                            int forward) {
   __shared__ DecTables t;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
@@ -160,14 +162,22 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunk) return;
-  const uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
+  uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
   ChunkState st = entry[i];
   uint64_t p = st.p;
   int k = st.k;
   uint64_t blocks = 0;
   int64_t b = WRITE ? (int64_t)first_block[i] : 0;
+  int c = i;  // the chunk being walked (a state pass may carry on into the following ones, see below)
+  // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
+  uint64_t p0 = p, w0 = window(s, p);
+walk:
   while (p < end) {
-    const uint64_t w = window(s, p);
+    if (p - p0 > 57 - 31) {
+      p0 = p;
+      w0 = window(s, p);
+    }
+    const uint64_t w = w0 << (p - p0);
     int len;
     if (k == 0) {
       const int sz = decode_symbol(t.dc.look8, t.dc.maxcode, t.dc.valoff, t.dc.vals, w, len) & 15;
@@ -209,14 +219,30 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
     }
   }
   if (!WRITE) {
-    const ChunkState old = exit_state[i];
-    if (old.p != p || old.k != k) *changed = 1;
-    ChunkState ns;
-    ns.p = p;
-    ns.k = k;
-    ns.pad = 0;
-    exit_state[i] = ns;
-    nblocks[i] = blocks;
+    const ChunkState old = exit_state[c];
+    const bool same = old.p == p && old.k == k;
+    if (!same) {
+      *changed = 1;
+      ChunkState ns;
+      ns.p = p;
+      ns.k = k;
+      ns.pad = 0;
+      exit_state[c] = ns;
+    }
+    if (c == i || !same) nblocks[c] = blocks;
+    // Where the stream is periodic (a blank margin: every block the same six bits) a wrong parse can be
+    // self-consistent, walks never re-synchronise and exactness would advance one chunk per round.  So a walk
+    // that arrives at a border in a state other than the published one carries that state on through the
+    // following chunks (up to `forward` of them: none in the first rounds, when most published states are still
+    // guesses, then doubling) instead of waiting for the next round.  Several threads may then write one
+    // chunk's state in a round; whatever survives is only a better or worse guess — the loop on the host ends
+    // only after a round in which every chunk reproduced its published state from its predecessor's.
+    if (!same && c + 1 < nchunk && c - i < forward && p < total_bits) {
+      ++c;
+      blocks = 0;
+      end = min((uint64_t)(c + 1) * CHUNK_BITS, total_bits);
+      goto walk;
+    }
   }
 }
 
@@ -542,18 +568,23 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
     hipLaunchKernelGGL(decode_chunks_kernel<false>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
-                       (const uint64_t*)nullptr, (int64_t)0, (int16_t*)nullptr, (int32_t*)nullptr);
+                       (const uint64_t*)nullptr, (int64_t)0, (int16_t*)nullptr, (int32_t*)nullptr,
+                       rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)));
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;
     OGD_HIP(hipMemcpyAsync(&changed, dflag.p, sizeof changed, hipMemcpyDeviceToHost, st));
     OGD_HIP(hipStreamSynchronize(st));
     ++rounds;
     if (!changed) break;
-    OGD_REQUIRE(rounds <= nchunk + 1, "JPEG chunk states did not settle");  // cannot happen: chunk r is exact after round r
+    // Chunk r is exact after round r, so this ends after nchunk rounds at the latest; real scans settle in 3 - 4.
+    // A scan that has not settled after 1024 rounds is damaged or adversarial: leave it to the caller's decoder.
+    if (rounds > 1024 || rounds > nchunk + 1)
+      return fail(OGD_ERR_RUNTIME, "JPEG chunk states did not settle in %d rounds", rounds);
     hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>());
     OGD_TRY(check_launch("shift_states_kernel"));
   }
   // the last round ran from entry = shifted exits of the round before and reproduced them: entry is exact
+  if (std::getenv("OGD_JPEG_DEBUG")) fprintf(stderr, "ogd_jpeg_decode: %d chunks settled in %d rounds\n", nchunk, rounds);
 
   // D3
   OGD_TRY(scan_u64(dtmp2, dnb.as<uint64_t>(), nchunk + 1, st));
@@ -571,7 +602,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
   hipLaunchKernelGGL(decode_chunks_kernel<true>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
-                     dnb.as<uint64_t>(), nblk, dcoef.as<int16_t>(), ddc.as<int32_t>());
+                     dnb.as<uint64_t>(), nblk, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0);
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
   size_t sb = 0;
   OGD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));

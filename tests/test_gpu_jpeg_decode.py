@@ -116,3 +116,23 @@ def test_resident_page_from_a_scan_file(gpu):
 		got = page.dewarp(nodes, 25)
 	assert np.array_equal(got, gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
 	assert gpu.DevicePage.from_jpeg(ojpeg.save_gray(np.zeros((16, 16), np.uint8), progressive=True)) is None
+
+
+def test_damaged_scans_never_fault_or_hang(gpu):
+	"""Bytes of the entropy-coded segment overwritten at random: the decoder either produces an image (what it
+	shows is undefined, as with any decoder) or hands the file back (None) — it must not fault, hang or raise
+	anything but OgdError for a structurally broken file."""
+	rng = np.random.default_rng(12)
+	data = bytearray(ojpeg.save_gray(synth.text_page(rng, (512, 384)), quality=80))
+	start = data.index(b"\xff\xda") + 10
+	for trial in range(12):
+		bad = bytearray(data)
+		for pos in rng.integers(start, len(bad) - 2, size=1 + trial * 8):
+			bad[pos] = int(rng.integers(0, 255))  # never 0xFF: the marker structure stays intact
+		try:
+			out = gpu.jpeg_decode_gray(bytes(bad))
+		except gpu.OgdError:
+			continue
+		assert out is None or out.shape == (384, 512)
+	# a healthy file still decodes afterwards (nothing was left in a bad state)
+	assert np.array_equal(gpu.jpeg_decode_gray(bytes(data)), _pil_decode(bytes(data)))
