@@ -116,10 +116,12 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
 
 /* ---- N4: decoding the page image ------------------------------------------------------------------
  * ref: origami/core/page.py:82-84 (`PIL.Image.open(path).convert("L")`).  A baseline JPEG decoder on the device
- * for 8-bit, one-component (grayscale) Huffman files without restart markers: the pixels PIL / libjpeg-turbo
- * decode, bit for bit (Huffman decoding in parallel by fixed-point iteration over 1024-bit chunks, islow IDCT).
+ * for 8-bit Huffman files without restart markers, one component (grayscale) or three (JFIF YCbCr in one
+ * interleaved scan, 4:4:4 / 4:2:2 / 4:2:0): the pixels `convert("L")` gives after PIL / libjpeg-turbo decoded the
+ * file, bit for bit (Huffman decoding in parallel by fixed-point iteration over 1024-bit chunks, islow IDCT,
+ * libjpeg's fancy chroma upsampling and YCbCr -> RGB tables, PIL's RGB -> L).
  * ogd_jpeg_info: size and component count of any JPEG file; *supported = 1 if this decoder covers it (else
- * ogd_last_error() names the reason and the caller keeps its own decoder — colour, progressive, DRI ...).
+ * ogd_last_error() names the reason and the caller keeps its own decoder — progressive, DRI, CMYK / Adobe ...).
  * ogd_jpeg_decode_gray: file bytes -> [H][W] uint8 (host, row stride in bytes); OGD_ERR_UNSUPPORTED for a file
  * outside the decoder's domain, OGD_ERR_RUNTIME for a scan with too few blocks.  _dev: output in device memory.
  */

@@ -316,8 +316,9 @@ def jpeg_info(data):
 
 
 def jpeg_decode_gray(data):
-	"""np.array(PIL.Image.open(file)) for a baseline grayscale JPEG, decoded on the device; None if the file is
-	outside the decoder's domain (colour, progressive, restart intervals ...: the caller keeps PIL)."""
+	"""np.array(PIL.Image.open(file)) for a baseline JPEG (grayscale, or YCbCr converted to "L" as PIL does), decoded on
+	the device; None if the file is outside the decoder's domain (progressive, restart intervals, CMYK ...: the
+	caller keeps PIL)."""
 	buf = np.frombuffer(data, dtype=np.uint8)
 	H, W, nc, ok = jpeg_info(data)
 	if not ok:

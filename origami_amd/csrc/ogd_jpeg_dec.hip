@@ -1,8 +1,10 @@
 // N4 — decoding the page image (ref: origami/core/page.py:82-84, `PIL.Image.open(path).convert("L")`): the
 // 0.15 - 0.2 s libjpeg spends per broadsheet scan are what every stage that opens a page pays first.
-// This is a baseline JPEG decoder for one-component (grayscale) 8-bit Huffman files without restart markers;
-// its pixels are the ones PIL / libjpeg-turbo produce, bit for bit (tests/ compare with PIL itself).  Anything
-// else (colour, progressive, arithmetic coding, 12 bit, DRI) returns OGD_ERR_UNSUPPORTED and the caller keeps PIL.
+// This is a baseline JPEG decoder for 8-bit Huffman files without restart markers: one component (grayscale), or
+// three (YCbCr, one interleaved scan, luma sampled 1x1, 2x1 or 2x2) converted to "L" the way PIL does it after
+// libjpeg's fancy upsampling and YCbCr -> RGB.  Its pixels are the ones `Image.open(f).convert("L")` gives, bit
+// for bit (tests/ compare with PIL itself).  Anything else (progressive, arithmetic coding, 12 bit, DRI, CMYK,
+// Adobe files) returns OGD_ERR_UNSUPPORTED and the caller keeps PIL.
 //
 // Restated from ITU T.81 and libjpeg's conventions: Huffman decoding (F.2.2), DC prediction, dequantisation,
 // inverse DCT "islow" (13-bit constants, 2 extra bits after the column pass, final shift by 18), sample =
@@ -39,8 +41,14 @@ struct DecHuff {        // one Huffman table, decoder form
   uint8_t vals[256];
 };
 struct DecTables {
-  DecHuff dc, ac;
-  uint16_t quant[64];  // natural order
+  DecHuff dc[2], ac[2];
+  uint16_t quant[3][64];         // natural order, per component
+  uint8_t blk_comp[16];          // component of block m of an MCU
+  uint8_t dc_sel[4], ac_sel[4];  // per component: index into dc[] / ac[]
+  int32_t bpm;                   // blocks per MCU
+  int32_t n0;                    // blocks of component 0 per MCU (h0 * v0)
+  int32_t base[3];               // first coefficient slot of each component
+  int32_t ntot;                  // slots in all
 };
 
 static bool build_dec_huff(const uint8_t* bits, const uint8_t* vals, int nvals, DecHuff& h) {
@@ -139,7 +147,7 @@ __device__ __forceinline__ int decode_symbol(const uint16_t* __restrict__ look8,
 struct ChunkState {
   uint64_t p;  // bit position of the next symbol
   int32_t k;   // index of the next coefficient of the current block (0: a DC symbol comes next)
-  int32_t pad;
+  int32_t m;   // index of the current block inside its MCU
 };
 
 // Walks chunk `i` from the exit state of chunk i - 1.  WRITE = false: publishes the exit state (and whether it
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
                                                             const ChunkState* __restrict__ entry,  // [nchunk]: exit of i - 1
                                                             ChunkState* __restrict__ exit_state,    // [nchunk]
                                                             uint64_t* __restrict__ nblocks, int* __restrict__ changed,
-                                                            const uint64_t* __restrict__ first_block, int64_t nblk,
+                                                            const uint64_t* __restrict__ first_block, int64_t nmcu,
                                                             int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff,
                                                             int forward) {
   __shared__ DecTables t;
@@ -165,9 +173,10 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
   ChunkState st = entry[i];
   uint64_t p = st.p;
-  int k = st.k;
+  int k = st.k, m = st.m;
   uint64_t blocks = 0;
-  int64_t b = WRITE ? (int64_t)first_block[i] : 0;
+  int64_t mcu = WRITE ? (int64_t)(first_block[i] / (uint64_t)t.bpm) : 0;  // blocks before this chunk: whole MCUs + m
+  const size_t ntot = (size_t)t.ntot;
   int c = i;  // the chunk being walked (a state pass may carry on into the following ones, see below)
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
   uint64_t p0 = p, w0 = window(s, p);
@@ -179,28 +188,33 @@ walk:
     }
     const uint64_t w = w0 << (p - p0);
     int len;
+    const int comp = t.blk_comp[m];
+    // coefficient slot of the current block: component-major, stream order inside a component
+    const size_t slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
     if (k == 0) {
-      const int sz = decode_symbol(t.dc.look8, t.dc.maxcode, t.dc.valoff, t.dc.vals, w, len) & 15;
-      if (WRITE && b < nblk) {
+      const DecHuff& hd = t.dc[t.dc_sel[comp]];
+      const int sz = decode_symbol(hd.look8, hd.maxcode, hd.valoff, hd.vals, w, len) & 15;
+      if (WRITE && mcu < nmcu) {
         int v = 0;
         if (sz) {
           v = (int)((w << len) >> (64 - sz));
           if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
         }
-        dcdiff[b] = v;
+        dcdiff[slot] = v;
       }
       p += (uint64_t)(len + sz);
       k = 1;
     } else {
-      const int rs = decode_symbol(t.ac.look8, t.ac.maxcode, t.ac.valoff, t.ac.vals, w, len);
+      const DecHuff& ha = t.ac[t.ac_sel[comp]];
+      const int rs = decode_symbol(ha.look8, ha.maxcode, ha.valoff, ha.vals, w, len);
       const int r = rs >> 4, sz = rs & 15;
       if (sz) {
         k += r;
-        if (WRITE && b < nblk && k < 64) {
+        if (WRITE && mcu < nmcu && k < 64) {
           int v = (int)((w << len) >> (64 - sz));
           if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
-          // zig-zag position k of block b: [8 groups][block] x 8 int16 (the encoder's layout)
-          coef[((size_t)(k >> 3) * (size_t)nblk + (size_t)b) * 8 + (k & 7)] = (int16_t)v;
+          // zig-zag position k of the block: [8 groups][slot] x 8 int16 (the encoder's layout)
+          coef[((size_t)(k >> 3) * ntot + slot) * 8 + (k & 7)] = (int16_t)v;
         }
         ++k;
         p += (uint64_t)(len + sz);
@@ -214,19 +228,22 @@ walk:
       if (k >= 64) {
         k = 0;
         ++blocks;
-        ++b;
+        if (++m >= t.bpm) {
+          m = 0;
+          ++mcu;
+        }
       }
     }
   }
   if (!WRITE) {
     const ChunkState old = exit_state[c];
-    const bool same = old.p == p && old.k == k;
+    const bool same = old.p == p && old.k == k && old.m == m;
     if (!same) {
       *changed = 1;
       ChunkState ns;
       ns.p = p;
       ns.k = k;
-      ns.pad = 0;
+      ns.m = m;
       exit_state[c] = ns;
     }
     if (c == i || !same) nblocks[c] = blocks;
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256) void shift_states_kernel(const ChunkState* __r
     ChunkState z;
     z.p = 0;
     z.k = 0;
-    z.pad = 0;
+    z.m = 0;
     entry[0] = z;
   } else {
     entry[i] = exit_state[i - 1];
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void init_states_kernel(int nchunk, ChunkState
   ChunkState z;
   z.p = (uint64_t)i * CHUNK_BITS;
   z.k = 0;
-  z.pad = 0;
+  z.m = 0;
   entry[i] = z;
   z.p = ~0ull;
   exit_state[i] = z;
@@ -332,27 +349,39 @@ __device__ __forceinline__ void idct8(int& d0, int& d1, int& d2, int& d3, int& d
   d4 = (tmp13 - t0 + R) >> SH;
 }
 
+// Where the samples of a component go: its plane, the part of it that exists, how its blocks are laid out.
+struct Planes {
+  uint8_t* p[3];
+  ptrdiff_t stride[3];
+  int W[3], H[3];  // stores are clipped to this
+  int mcux;        // MCUs per row
+  int h0, v0;      // blocks of component 0 per MCU, horizontally and vertically
+};
+
 __global__ __launch_bounds__(256) void idct_kernel(const uint4* __restrict__ coef, const int32_t* __restrict__ dc,
-                                                   const DecTables* __restrict__ tabs, int nbx, int nblk, int H, int W,
-                                                   uint8_t* __restrict__ img, ptrdiff_t stride) {
-  __shared__ int s_q[64];  // dequantisation factors in zig-zag order
+                                                   const DecTables* __restrict__ tabs, const Planes pl) {
+  __shared__ int s_q[3][64];  // dequantisation factors in zig-zag order
+  __shared__ int s_base[3];
   constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-  if (threadIdx.x < 64) s_q[threadIdx.x] = tabs->quant[ZZ[threadIdx.x]];
+  if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = tabs->quant[threadIdx.x >> 6][ZZ[threadIdx.x & 63]];
+  if (threadIdx.x < 3) s_base[threadIdx.x] = tabs->base[threadIdx.x];
   __syncthreads();
+  const int ntot = tabs->ntot;
   const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= nblk) return;
+  if (b >= ntot) return;
+  const int comp = b >= s_base[2] && s_base[2] > 0 ? 2 : (b >= s_base[1] && s_base[1] > 0 ? 1 : 0);
   int d[64];
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    const uint4 v = coef[(size_t)g * nblk + b];
+    const uint4 v = coef[(size_t)g * ntot + b];
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = g * 8 + j;
       const int c = (int)(int16_t)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-      d[ZZ[k]] = (k == 0 ? dc[b] : c) * s_q[k];
+      d[ZZ[k]] = (k == 0 ? dc[b] : c) * s_q[comp][k];
     }
   }
 #pragma unroll
@@ -361,12 +390,25 @@ __global__ __launch_bounds__(256) void idct_kernel(const uint4* __restrict__ coe
 #pragma unroll
   for (int r = 0; r < 8; ++r)  // pass 2: rows
     idct8<2>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
-  const int by = b / nbx, bx = b - by * nbx;
-  const int x0 = bx * 8, y0 = by * 8;
+  // block position: component 0 holds h0 x v0 blocks per MCU in raster order, the others one
+  const int local = b - s_base[comp];
+  int bx, by;
+  if (comp == 0) {
+    const int n0 = pl.h0 * pl.v0;
+    const int mcu = local / n0, j = local - mcu * n0;
+    const int my = mcu / pl.mcux, mx = mcu - my * pl.mcux;
+    bx = mx * pl.h0 + j % pl.h0;
+    by = my * pl.v0 + j / pl.h0;
+  } else {
+    by = local / pl.mcux;
+    bx = local - by * pl.mcux;
+  }
+  const int x0 = bx * 8, y0 = by * 8, W = pl.W[comp], H = pl.H[comp];
+  if (x0 >= W) return;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     if (y0 + r >= H) break;
-    uint8_t* row = img + (ptrdiff_t)(y0 + r) * stride + x0;
+    uint8_t* row = pl.p[comp] + (ptrdiff_t)(y0 + r) * pl.stride[comp] + x0;
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -383,10 +425,50 @@ __global__ __launch_bounds__(256) void idct_kernel(const uint4* __restrict__ coe
   }
 }
 
+// ---- D7: YCbCr planes -> "L" ---------------------------------------------------------------------------------
+// libjpeg's fancy ("triangle") chroma upsampling, its YCbCr -> RGB tables and PIL's RGB -> L:
+//   h2v2: colsum = 3 * near row + far row (far: the row above for even output rows, below for odd ones; edge rows
+//         repeat), out = (3 * colsum[x/2] + colsum[x/2 -+ 1] + (8 | 7)) >> 4 (left neighbour and 8 for even x)
+//   h2v1: out = (3 * c[x/2] + c[x/2 -+ 1] + (1 | 2)) >> 2;  edge columns repeat their own sample
+//   R = Y + ((91881 Cr + 32768) >> 16), G = Y + ((-22554 Cb - 46802 Cr + 32768) >> 16), B = Y + ((116130 Cb + 32768) >> 16)
+//   with Cb, Cr - 128, clamped;  L = (19595 R + 38470 G + 7471 B + 32768) >> 16
+__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ c, ptrdiff_t stride, int cw, int ch, int h0, int v0,
+                                         int x, int y) {
+  if (h0 == 1) return c[(ptrdiff_t)y * stride + x];  // h1v1
+  const int xc = x >> 1;
+  const int xn = min(max(xc + ((x & 1) ? 1 : -1), 0), cw - 1);
+  if (v0 == 1) {  // h2v1
+    const uint8_t* r = c + (ptrdiff_t)y * stride;
+    return (3 * r[xc] + r[xn] + ((x & 1) ? 2 : 1)) >> 2;
+  }
+  const int yc = y >> 1;
+  const int yf = min(max(yc + ((y & 1) ? 1 : -1), 0), ch - 1);
+  const uint8_t* rn = c + (ptrdiff_t)yc * stride;
+  const uint8_t* rf = c + (ptrdiff_t)yf * stride;
+  const int cs = 3 * rn[xc] + rf[xc], cn = 3 * rn[xn] + rf[xn];
+  return (3 * cs + cn + ((x & 1) ? 7 : 8)) >> 4;
+}
+
+__global__ __launch_bounds__(256) void ycc_to_l_kernel(const uint8_t* __restrict__ py, ptrdiff_t sy,
+                                                       const uint8_t* __restrict__ pcb, const uint8_t* __restrict__ pcr,
+                                                       ptrdiff_t sc, int cw, int ch, int h0, int v0, int H, int W,
+                                                       uint8_t* __restrict__ out, ptrdiff_t so) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W || y >= H) return;
+  const int Y = py[(ptrdiff_t)y * sy + x];
+  const int cb = chroma_at(pcb, sc, cw, ch, h0, v0, x, y) - 128;
+  const int cr = chroma_at(pcr, sc, cw, ch, h0, v0, x, y) - 128;
+  const int R = min(max(Y + ((91881 * cr + 32768) >> 16), 0), 255);
+  const int G = min(max(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0), 255);
+  const int B = min(max(Y + ((116130 * cb + 32768) >> 16), 0), 255);
+  out[(ptrdiff_t)y * so + x] = (uint8_t)((R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16);
+}
+
 // ---- host: file structure --------------------------------------------------------------------------------
 
 struct JpegInfo {
   int H = 0, W = 0, ncomp = 0;
+  int h0 = 1, v0 = 1;  // luma blocks per MCU (three components)
   bool supported = false;
   const char* why = "";
   size_t scan_begin = 0, scan_end = 0;
@@ -406,8 +488,9 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   uint8_t qt[4][64];
   bool have_q[4] = {false, false, false, false};
   struct RawHuff { uint8_t bits[16]; uint8_t vals[256]; int n = -1; } hd[4], ha[4];
-  int tq = -1, td = -1, ta = -1, comp_id = -1;
-  bool have_sof = false;
+  int tq[3] = {-1, -1, -1}, td[3] = {-1, -1, -1}, ta[3] = {-1, -1, -1}, comp_id[3] = {-1, -1, -1};
+  int hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
+  bool have_sof = false, have_jfif = false;
   size_t p = 2;
   while (true) {
     OGD_REQUIRE(p + 4 <= n, "truncated JPEG file");
@@ -457,12 +540,24 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
       info.ncomp = s[5];
       have_sof = true;
       if (s[0] != 8) JP_UNSUP("sample precision other than 8 bits");
-      if (info.ncomp != 1) JP_UNSUP("more than one component");
-      OGD_REQUIRE(sl >= 9, "truncated SOF segment");
-      comp_id = s[6];
-      tq = s[8];
-      OGD_REQUIRE(tq < 4, "bad quantisation table selector");
+      if (info.ncomp != 1 && info.ncomp != 3) JP_UNSUP("neither one nor three components");
+      OGD_REQUIRE(sl >= 6 + 3 * (size_t)info.ncomp, "truncated SOF segment");
+      for (int c = 0; c < info.ncomp; ++c) {
+        comp_id[c] = s[6 + 3 * c];
+        hs[c] = s[7 + 3 * c] >> 4;
+        vs[c] = s[7 + 3 * c] & 15;
+        tq[c] = s[8 + 3 * c];
+        OGD_REQUIRE(tq[c] < 4 && hs[c] >= 1 && vs[c] >= 1, "bad component specification");
+      }
       if (info.H == 0 || info.W == 0) JP_UNSUP("image height defined by a DNL marker");
+      if (info.ncomp == 3) {
+        if (comp_id[0] != 1 || comp_id[1] != 2 || comp_id[2] != 3) JP_UNSUP("component ids other than 1, 2, 3 (not YCbCr)");
+        if (hs[1] != 1 || vs[1] != 1 || hs[2] != 1 || vs[2] != 1) JP_UNSUP("subsampled luma or oversampled chroma");
+        if (!((hs[0] == 1 && vs[0] == 1) || (hs[0] == 2 && vs[0] == 1) || (hs[0] == 2 && vs[0] == 2)))
+          JP_UNSUP("luma sampling other than 1x1, 2x1, 2x2");
+        // libjpeg upsamples the chroma of narrow images by replication, not with the triangle filter
+        if (hs[0] == 2 && (info.W + 1) / 2 <= 2) JP_UNSUP("image too narrow for fancy upsampling");
+      }
     } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       if (sl >= 6) {
         info.H = (s[1] << 8) | s[2];
@@ -473,19 +568,31 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
     } else if (m == 0xDD) {
       OGD_REQUIRE(sl >= 2, "truncated DRI segment");
       if (((s[0] << 8) | s[1]) != 0) JP_UNSUP("restart intervals");
+    } else if (m == 0xE0) {
+      if (sl >= 5 && std::memcmp(s, "JFIF", 5) == 0) have_jfif = true;
+    } else if (m == 0xEE) {
+      if (sl >= 5 && std::memcmp(s, "Adobe", 5) == 0) JP_UNSUP("Adobe colour transform marker");
     } else if (m == 0xDA) {
       OGD_REQUIRE(have_sof, "SOS before SOF");
-      OGD_REQUIRE(sl >= 6 && s[0] == 1 && s[1] == comp_id, "bad SOS segment");
-      td = s[2] >> 4;
-      ta = s[2] & 15;
-      OGD_REQUIRE(td < 4 && ta < 4, "bad Huffman table selector");
-      if (s[3] != 0 || s[4] != 63 || s[5] != 0) JP_UNSUP("spectral selection / successive approximation");
+      OGD_REQUIRE(sl >= 1, "bad SOS segment");
+      if (s[0] != info.ncomp) JP_UNSUP("scan does not hold all components (non-interleaved file)");
+      OGD_REQUIRE(sl >= 4 + 2 * (size_t)info.ncomp, "bad SOS segment");
+      for (int c = 0; c < info.ncomp; ++c) {
+        OGD_REQUIRE(s[1 + 2 * c] == comp_id[c], "bad SOS segment (component order)");
+        td[c] = s[2 + 2 * c] >> 4;
+        ta[c] = s[2 + 2 * c] & 15;
+        OGD_REQUIRE(td[c] < 4 && ta[c] < 4, "bad Huffman table selector");
+      }
+      const uint8_t* e = s + 1 + 2 * info.ncomp;
+      if (e[0] != 0 || e[1] != 63 || e[2] != 0) JP_UNSUP("spectral selection / successive approximation");
       p += len;
       break;
     }
     p += len;
   }
-  OGD_REQUIRE(have_q[tq] && hd[td].n >= 0 && ha[ta].n >= 0, "JPEG scan refers to a table that was not defined");
+  if (info.ncomp == 3 && !have_jfif) JP_UNSUP("three components without a JFIF header (colour space not certain)");
+  for (int c = 0; c < info.ncomp; ++c)
+    OGD_REQUIRE(have_q[tq[c]] && hd[td[c]].n >= 0 && ha[ta[c]].n >= 0, "JPEG scan refers to a table that was not defined");
   // the entropy-coded segment ends at the first marker that is not stuffing
   size_t e = p;
   while (true) {
@@ -501,10 +608,39 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   if (f[e + 1] != 0xD9) JP_UNSUP("marker inside the scan");  // RSTn, further scans, fill bytes
   info.scan_begin = p;
   info.scan_end = e;
-  for (int k = 0; k < 64; ++k) info.tabs.quant[k] = qt[tq][k];
-  OGD_REQUIRE(build_dec_huff(hd[td].bits, hd[td].vals, hd[td].n, info.tabs.dc) &&
-                  build_dec_huff(ha[ta].bits, ha[ta].vals, ha[ta].n, info.tabs.ac),
-              "inconsistent Huffman table");
+  DecTables& T = info.tabs;
+  std::memset(&T, 0, sizeof T);
+  // at most two DC and two AC tables in use (baseline)
+  int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
+  for (int c = 0; c < info.ncomp; ++c) {
+    for (int k = 0; k < 64; ++k) T.quant[c][k] = qt[tq[c]][k];
+    int sd = td[c] == dc_ids[0] ? 0 : td[c] == dc_ids[1] ? 1 : dc_ids[0] < 0 ? 0 : dc_ids[1] < 0 ? 1 : -1;
+    int sa = ta[c] == ac_ids[0] ? 0 : ta[c] == ac_ids[1] ? 1 : ac_ids[0] < 0 ? 0 : ac_ids[1] < 0 ? 1 : -1;
+    if (sd < 0 || sa < 0) JP_UNSUP("more than two Huffman tables of a class in use");
+    dc_ids[sd] = td[c];
+    ac_ids[sa] = ta[c];
+    T.dc_sel[c] = (uint8_t)sd;
+    T.ac_sel[c] = (uint8_t)sa;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (dc_ids[k] >= 0)
+      OGD_REQUIRE(build_dec_huff(hd[dc_ids[k]].bits, hd[dc_ids[k]].vals, hd[dc_ids[k]].n, T.dc[k]), "inconsistent Huffman table");
+    if (ac_ids[k] >= 0)
+      OGD_REQUIRE(build_dec_huff(ha[ac_ids[k]].bits, ha[ac_ids[k]].vals, ha[ac_ids[k]].n, T.ac[k]), "inconsistent Huffman table");
+  }
+  // a one-component scan is not interleaved: one block per MCU whatever its sampling factors say
+  info.h0 = info.ncomp == 3 ? hs[0] : 1;
+  info.v0 = info.ncomp == 3 ? vs[0] : 1;
+  T.n0 = info.h0 * info.v0;
+  T.bpm = info.ncomp == 3 ? T.n0 + 2 : 1;
+  for (int m2 = 0; m2 < T.bpm; ++m2) T.blk_comp[m2] = (uint8_t)(m2 < T.n0 ? 0 : m2 - T.n0 + 1);
+  const int64_t mcux = (info.W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (info.H + 8 * info.v0 - 1) / (8 * info.v0);
+  const int64_t nmcu = mcux * mcuy;
+  OGD_REQUIRE(nmcu * T.bpm < INT_MAX - 256, "too many blocks");
+  T.base[0] = 0;
+  T.base[1] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0) : 0;
+  T.base[2] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0 + nmcu) : 0;
+  T.ntot = (int32_t)(nmcu * T.bpm);
   info.supported = true;
   return OGD_OK;
 }
@@ -519,9 +655,9 @@ static int scan_u64(DevBuf& tmp, uint64_t* d, int count, hipStream_t st) {
 
 static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride, hipStream_t st) {
   const int H = info.H, W = info.W;
-  const int nbx = (W + 7) / 8, nby = (H + 7) / 8;
-  const int64_t nblk = (int64_t)nbx * nby;
-  OGD_REQUIRE(nblk < INT_MAX - 256, "too many blocks");
+  const int mcux = (W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (H + 8 * info.v0 - 1) / (8 * info.v0);
+  const int64_t nmcu = (int64_t)mcux * mcuy;
+  const int64_t nblk = info.tabs.ntot;  // coefficient slots = blocks of all components
   const uint64_t nscan = info.scan_end - info.scan_begin;
   OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
 
@@ -568,7 +704,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
     hipLaunchKernelGGL(decode_chunks_kernel<false>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
-                       (const uint64_t*)nullptr, (int64_t)0, (int16_t*)nullptr, (int32_t*)nullptr,
+                       (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
                        rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)));
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;
@@ -602,15 +738,57 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
   hipLaunchKernelGGL(decode_chunks_kernel<true>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
-                     dnb.as<uint64_t>(), nblk, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0);
+                     dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0);
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
-  size_t sb = 0;
-  OGD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));
-  OGD_TRY(dtmp3.alloc(sb));
-  OGD_HIP(hipcub::DeviceScan::InclusiveSum(dtmp3.p, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));
+  // D5: DC prediction runs per component, in stream order: one inclusive scan per component's slots
+  DevBuf dplanes;
+  {
+    const int ncomp = info.ncomp;
+    const int32_t starts[4] = {info.tabs.base[0], ncomp == 3 ? info.tabs.base[1] : (int32_t)nblk,
+                               ncomp == 3 ? info.tabs.base[2] : (int32_t)nblk, (int32_t)nblk};
+    size_t sb = 0;
+    OGD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, sb, ddc.as<int32_t>(), ddc.as<int32_t>(), (int)nblk, st));
+    OGD_TRY(dtmp3.alloc(sb));
+    for (int c = 0; c < ncomp; ++c) {
+      const int cnt = starts[c + 1] - starts[c];
+      size_t sbc = sb;
+      OGD_HIP(hipcub::DeviceScan::InclusiveSum(dtmp3.p, sbc, ddc.as<int32_t>() + starts[c], ddc.as<int32_t>() + starts[c], cnt, st));
+    }
+  }
+  // D6 (+ D7)
+  Planes pl;
+  std::memset(&pl, 0, sizeof pl);
+  pl.mcux = mcux;
+  pl.h0 = info.h0;
+  pl.v0 = info.v0;
+  const int cw = (W + info.h0 - 1) / info.h0, ch = (H + info.v0 - 1) / info.v0;  // libjpeg's downsampled size
+  if (info.ncomp == 1) {
+    pl.p[0] = d_img;
+    pl.stride[0] = stride;
+    pl.W[0] = W;
+    pl.H[0] = H;
+  } else {
+    const size_t ysz = (size_t)W * H, csz = (size_t)cw * ch;
+    OGD_TRY(dplanes.alloc(ysz + 2 * csz));
+    pl.p[0] = dplanes.as<uint8_t>();
+    pl.p[1] = pl.p[0] + ysz;
+    pl.p[2] = pl.p[1] + csz;
+    pl.stride[0] = W;
+    pl.stride[1] = pl.stride[2] = cw;
+    pl.W[0] = W;
+    pl.H[0] = H;
+    pl.W[1] = pl.W[2] = cw;
+    pl.H[1] = pl.H[2] = ch;
+  }
   hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), blk, 0, st, dcoef.as<uint4>(), ddc.as<int32_t>(),
-                     tabs, nbx, (int)nblk, H, W, d_img, stride);
+                     tabs, pl);
   OGD_TRY(check_launch("idct_kernel"));
+  if (info.ncomp == 3) {
+    OGD_REQUIRE(H <= 65535, "image too tall");
+    hipLaunchKernelGGL(ycc_to_l_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), blk, 0, st, pl.p[0], pl.stride[0],
+                       pl.p[1], pl.p[2], pl.stride[1], cw, ch, info.h0, info.v0, H, W, d_img, stride);
+    OGD_TRY(check_launch("ycc_to_l_kernel"));
+  }
   OGD_HIP(hipStreamSynchronize(st));  // the scratch buffers go back to the block cache on return
   return OGD_OK;
 }

@@ -55,8 +55,8 @@ class Page:
 		return self._warped
 
 	def _decode_on_device(self):
-		"""A baseline grayscale JPEG scan is decoded by ogd_jpeg_decode_gray: the pixels PIL would give, bit for
-		bit, in a few ms instead of 0.15 s.  Any other file (PNG, colour or progressive JPEG, JPEG 2000 ...)
+		"""A baseline JPEG scan (grayscale or YCbCr colour) is decoded by ogd_jpeg_decode_gray: the pixels PIL would give, bit for
+		bit, in a few ms instead of 0.15 s.  Any other file (PNG, progressive or CMYK JPEG, JPEG 2000 ...)
 		returns None and goes through PIL as in the reference (ref: page.py:82-84)."""
 		if not self._on_device_format():
 			return None

@@ -60,15 +60,94 @@ def test_files_outside_the_domain_are_refused_not_misdecoded(gpu):
 	rng = np.random.default_rng(4)
 	rgb = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
 	buf = io.BytesIO()
-	PIL.Image.fromarray(rgb).save(buf, format="JPEG")
+	PIL.Image.fromarray(rgb).convert("CMYK").save(buf, format="JPEG")
+	assert gpu.jpeg_info(buf.getvalue())[3] is False  # Adobe marker, four components
+	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rgb).save(buf, format="JPEG", progressive=True)
 	assert gpu.jpeg_info(buf.getvalue())[2:] == (3, False)
 	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rgb[:, :3]).save(buf, format="JPEG", subsampling=2)  # libjpeg upsamples such strips plainly
+	assert gpu.jpeg_info(buf.getvalue())[2:] == (3, False)
 	buf = io.BytesIO()
 	PIL.Image.fromarray(rgb[:, :, 0]).save(buf, format="JPEG", progressive=True)
 	assert gpu.jpeg_info(buf.getvalue())[3] is False
 	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
 	with pytest.raises(gpu.OgdError):
 		gpu.jpeg_info(b"not a jpeg file at all")
+
+
+def _colour_file(rgb, **params):
+	buf = io.BytesIO()
+	PIL.Image.fromarray(rgb).save(buf, format="JPEG", **params)
+	return buf.getvalue()
+
+
+def _check_colour(gpu, rgb, **params):
+	data = _colour_file(rgb, **params)
+	assert gpu.jpeg_info(data)[2:] == (3, True)
+	got = gpu.jpeg_decode_gray(data)
+	assert got is not None, "decoder refused a baseline YCbCr file"
+	want = _pil_decode(data)
+	assert got.shape == want.shape
+	assert np.array_equal(got, want), "%d pixels differ, max %d" % (
+		(got != want).sum(), np.abs(got.astype(int) - want).max())
+
+
+def _colour_page(rng, size):
+	"""A scan in colour: yellowed paper, dark text, a coloured stamp, sensor noise."""
+	W, H = size
+	text = synth.text_page(rng, size).astype(np.float32) / 255.0
+	paper = np.array([236, 222, 190], np.float32)
+	ink = np.array([40, 32, 36], np.float32)
+	rgb = ink + (paper - ink) * text[:, :, None]
+	yy, xx = np.mgrid[0:H, 0:W]
+	stamp = ((yy - H // 3) ** 2 + (xx - W // 2) ** 2) < (min(W, H) // 6) ** 2
+	rgb[stamp] = 0.5 * rgb[stamp] + 0.5 * np.array([200, 30, 40], np.float32)
+	rgb += rng.normal(0, 3, size=rgb.shape)
+	return np.clip(rgb, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(8, 8), (16, 16), (17, 33), (33, 17), (64, 64), (250, 301), (301, 250), (999, 778)])
+def test_colour_noise_images_of_ragged_sizes(gpu, shape, subsampling):
+	"""Three components, 4:4:4 / 4:2:2 / 4:2:0: libjpeg's fancy upsampling, YCbCr -> RGB, PIL's RGB -> L."""
+	rng = np.random.default_rng(shape[0] * 1000 + shape[1] + subsampling)
+	_check_colour(gpu, rng.integers(0, 256, size=shape + (3,), dtype=np.uint8), subsampling=subsampling, quality=90)
+
+
+@pytest.mark.parametrize("quality", [5, 50, 75, 95, 100])
+def test_colour_qualities_and_fitted_tables(gpu, quality):
+	rng = np.random.default_rng(100 + quality)
+	page = _colour_page(rng, (640, 480))
+	_check_colour(gpu, page, quality=quality)  # PIL's default: 4:2:0 below quality 90... whatever it picks
+	_check_colour(gpu, page, quality=quality, optimize=True, subsampling=1)
+	_check_colour(gpu, page, quality=quality, subsampling="4:4:4")
+
+
+def test_colour_flat_and_saturated_images(gpu):
+	for colour in ((0, 0, 0), (255, 255, 255), (255, 0, 0), (0, 255, 0), (0, 0, 255), (12, 200, 99)):
+		_check_colour(gpu, np.broadcast_to(np.array(colour, np.uint8), (120, 200, 3)).copy(), quality=100, subsampling=2)
+	yy, xx = np.mgrid[0:200, 0:312]
+	chk = (((yy // 3 + xx // 3) & 1) * 255).astype(np.uint8)
+	_check_colour(gpu, np.dstack([chk, 255 - chk, chk]), quality=100, subsampling=2)
+	_check_colour(gpu, np.dstack([chk, 255 - chk, chk]), quality=100, subsampling=0)
+
+
+def test_whole_colour_broadsheet_scan(gpu):
+	"""configs[1] size in colour, 4:2:0 (what scanners and PIL write by default)."""
+	rng = np.random.default_rng(8)
+	_check_colour(gpu, _colour_page(rng, (6000, 8000)), quality=85)
+
+
+def test_colour_scan_file_to_dewarped_file_on_the_device(gpu):
+	rng = np.random.default_rng(13)
+	size = (1100, 1500)
+	scan = _colour_file(_colour_page(rng, size), quality=88)
+	nodes = synth.Warp.random(rng, size).node_grid(25)
+	want = ojpeg.save_gray(gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
+	assert gpu.jpeg_dewarp_jpeg_gray(scan, nodes, 25) == want
 
 
 def test_truncated_scan_is_left_to_pil(gpu):
@@ -101,7 +180,7 @@ def test_scan_file_to_dewarped_file_on_the_device(gpu):
 	want = ojpeg.save_gray(gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
 	assert gpu.jpeg_dewarp_jpeg_gray(scan, nodes, 25) == want
 	buf = io.BytesIO()
-	PIL.Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(buf, format="JPEG")
+	PIL.Image.fromarray(rng.integers(0, 256, size=(64, 64), dtype=np.uint8)).save(buf, format="JPEG", progressive=True)
 	assert gpu.jpeg_dewarp_jpeg_gray(buf.getvalue(), nodes, 25) is None
 
 
