@@ -1,10 +1,11 @@
 // N4 — decoding the page image (ref: origami/core/page.py:82-84, `PIL.Image.open(path).convert("L")`): the
 // 0.15 - 0.2 s libjpeg spends per broadsheet scan are what every stage that opens a page pays first.
-// This is a baseline JPEG decoder for 8-bit Huffman files without restart markers: one component (grayscale), or
+// This is a baseline JPEG decoder for 8-bit Huffman files: one component (grayscale), or
 // three (YCbCr, one interleaved scan, luma sampled 1x1, 2x1 or 2x2) converted to "L" the way PIL does it after
 // libjpeg's fancy upsampling and YCbCr -> RGB.  Its pixels are the ones `Image.open(f).convert("L")` gives, bit
-// for bit (tests/ compare with PIL itself).  Anything else (progressive, arithmetic coding, 12 bit, DRI, CMYK,
-// Adobe files) returns OGD_ERR_UNSUPPORTED and the caller keeps PIL.
+// for bit (tests/ compare with PIL itself).  Scans with restart intervals (DRI) are decoded interval by interval.
+// Anything else (progressive, arithmetic coding, 12 bit, CMYK, Adobe files) returns OGD_ERR_UNSUPPORTED and the
+// caller keeps PIL.
 //
 // Restated from ITU T.81 and libjpeg's conventions: Huffman decoding (F.2.2), DC prediction, dequantisation,
 // inverse DCT "islow" (13-bit constants, 2 extra bits after the column pass, final shift by 18), sample =
@@ -151,8 +152,9 @@ struct ChunkState {
 };
 
 // Walks chunk `i` from the exit state of chunk i - 1.  WRITE = false: publishes the exit state (and whether it
-// changed) and the number of blocks completed.  WRITE = true: stores the coefficients.
-template <bool WRITE>
+// changed) and the number of blocks completed.  WRITE = true: stores the coefficients.  MULTI = false: one
+// component, one block per MCU, one pair of tables (the usual scan: no per-block table look-ups).
+template <bool WRITE, bool MULTI>
 __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __restrict__ s, uint64_t total_bits,
                                                             int nchunk, const DecTables* __restrict__ tabs,
                                                             const ChunkState* __restrict__ entry,  // [nchunk]: exit of i - 1
@@ -173,9 +175,10 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
   ChunkState st = entry[i];
   uint64_t p = st.p;
-  int k = st.k, m = st.m;
+  int k = st.k, m = MULTI ? st.m : 0;
   uint64_t blocks = 0;
-  int64_t mcu = WRITE ? (int64_t)(first_block[i] / (uint64_t)t.bpm) : 0;  // blocks before this chunk: whole MCUs + m
+  // blocks before this chunk: whole MCUs + m
+  int64_t mcu = WRITE ? (MULTI ? (int64_t)(first_block[i] / (uint64_t)t.bpm) : (int64_t)first_block[i]) : 0;
   const size_t ntot = (size_t)t.ntot;
   int c = i;  // the chunk being walked (a state pass may carry on into the following ones, see below)
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
@@ -188,11 +191,11 @@ walk:
     }
     const uint64_t w = w0 << (p - p0);
     int len;
-    const int comp = t.blk_comp[m];
+    const int comp = MULTI ? t.blk_comp[m] : 0;
     // coefficient slot of the current block: component-major, stream order inside a component
-    const size_t slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
+    const size_t slot = MULTI ? (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu) : (size_t)mcu;
     if (k == 0) {
-      const DecHuff& hd = t.dc[t.dc_sel[comp]];
+      const DecHuff& hd = t.dc[MULTI ? t.dc_sel[comp] : 0];
       const int sz = decode_symbol(hd.look8, hd.maxcode, hd.valoff, hd.vals, w, len) & 15;
       if (WRITE && mcu < nmcu) {
         int v = 0;
@@ -205,7 +208,7 @@ walk:
       p += (uint64_t)(len + sz);
       k = 1;
     } else {
-      const DecHuff& ha = t.ac[t.ac_sel[comp]];
+      const DecHuff& ha = t.ac[MULTI ? t.ac_sel[comp] : 0];
       const int rs = decode_symbol(ha.look8, ha.maxcode, ha.valoff, ha.vals, w, len);
       const int r = rs >> 4, sz = rs & 15;
       if (sz) {
@@ -228,7 +231,9 @@ walk:
       if (k >= 64) {
         k = 0;
         ++blocks;
-        if (++m >= t.bpm) {
+        if (!MULTI) {
+          ++mcu;
+        } else if (++m >= t.bpm) {
           m = 0;
           ++mcu;
         }
@@ -261,6 +266,91 @@ walk:
       goto walk;
     }
   }
+}
+
+
+// ---- D2' : scans with restart intervals ----------------------------------------------------------------
+// An RSTn marker byte-aligns the stream and resets the DC predictions (T.81 F.2.1.3.1 / libjpeg's
+// process_restart): every interval decodes on its own and knows its first MCU, so no chunk iteration is needed.
+// Thread = interval, reading the raw segment (stuffing still in place) byte by byte; DC values are accumulated
+// here (absolute values go to `dc`, no scan).  An interval whose data ends before its MCUs do sets *short_flag.
+__global__ __launch_bounds__(64) void decode_intervals_kernel(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ starts,
+                                                              int nint, const DecTables* __restrict__ tabs, int restart,
+                                                              int64_t nmcu, int16_t* __restrict__ coef,
+                                                              int32_t* __restrict__ dc, int* __restrict__ short_flag) {
+  __shared__ DecTables t;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+    for (int i = threadIdx.x; i < (int)(sizeof(DecTables) / 4); i += 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= nint) return;
+  uint64_t pos = starts[j];
+  const uint64_t end = starts[j + 1];  // the next interval's first byte (its marker lies in between: never read as data)
+  const uint64_t data_end = j + 1 < nint ? end - 2 : end;
+  uint64_t acc = 0;
+  int nbits = 0, over = 0;
+  int pred[3] = {0, 0, 0};
+  const size_t ntot = (size_t)t.ntot;
+  const int64_t mcu_end = min((int64_t)(j + 1) * restart, nmcu);
+  for (int64_t mcu = (int64_t)j * restart; mcu < mcu_end; ++mcu) {
+    for (int m = 0; m < t.bpm; ++m) {
+      const int comp = t.blk_comp[m];
+      const size_t slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
+      const DecHuff& hd = t.dc[t.dc_sel[comp]];
+      const DecHuff& ha = t.ac[t.ac_sel[comp]];
+      int k = 0;
+      while (k < 64) {
+        while (nbits <= 56) {  // refill: a symbol takes at most 16 + 15 bits
+          uint32_t b = 0;
+          if (pos < data_end) {
+            b = raw[pos++];
+            if (b == 0xFFu && pos < data_end && raw[pos] == 0) ++pos;
+          } else {
+            ++over;
+          }
+          acc |= (uint64_t)b << (56 - nbits);
+          nbits += 8;
+        }
+        int len;
+        if (k == 0) {
+          const int sz = decode_symbol(hd.look8, hd.maxcode, hd.valoff, hd.vals, acc, len) & 15;
+          int v = 0;
+          if (sz) {
+            v = (int)((acc << len) >> (64 - sz));
+            if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+          }
+          pred[comp] += v;
+          dc[slot] = pred[comp];
+          acc <<= len + sz;
+          nbits -= len + sz;
+          k = 1;
+        } else {
+          const int rs = decode_symbol(ha.look8, ha.maxcode, ha.valoff, ha.vals, acc, len);
+          const int r = rs >> 4, sz = rs & 15;
+          if (sz) {
+            k += r;
+            if (k < 64) {
+              int v = (int)((acc << len) >> (64 - sz));
+              if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+              coef[((size_t)(k >> 3) * ntot + slot) * 8 + (k & 7)] = (int16_t)v;
+            }
+            ++k;
+            acc <<= len + sz;
+            nbits -= len + sz;
+          } else {
+            k = r == 15 ? k + 16 : 64;
+            acc <<= len;
+            nbits -= len;
+          }
+        }
+      }
+    }
+  }
+  // bytes invented past the end of the interval that were actually consumed: the interval was cut short
+  if (over * 8 > nbits) *short_flag = 1;
 }
 
 // entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0)
@@ -432,36 +522,69 @@ __global__ __launch_bounds__(256) void idct_kernel(const uint4* __restrict__ coe
 //   h2v1: out = (3 * c[x/2] + c[x/2 -+ 1] + (1 | 2)) >> 2;  edge columns repeat their own sample
 //   R = Y + ((91881 Cr + 32768) >> 16), G = Y + ((-22554 Cb - 46802 Cr + 32768) >> 16), B = Y + ((116130 Cb + 32768) >> 16)
 //   with Cb, Cr - 128, clamped;  L = (19595 R + 38470 G + 7471 B + 32768) >> 16
-__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ c, ptrdiff_t stride, int cw, int ch, int h0, int v0,
-                                         int x, int y) {
-  if (h0 == 1) return c[(ptrdiff_t)y * stride + x];  // h1v1
-  const int xc = x >> 1;
-  const int xn = min(max(xc + ((x & 1) ? 1 : -1), 0), cw - 1);
-  if (v0 == 1) {  // h2v1
-    const uint8_t* r = c + (ptrdiff_t)y * stride;
-    return (3 * r[xc] + r[xn] + ((x & 1) ? 2 : 1)) >> 2;
-  }
-  const int yc = y >> 1;
-  const int yf = min(max(yc + ((y & 1) ? 1 : -1), 0), ch - 1);
-  const uint8_t* rn = c + (ptrdiff_t)yc * stride;
-  const uint8_t* rf = c + (ptrdiff_t)yf * stride;
-  const int cs = 3 * rn[xc] + rf[xc], cn = 3 * rn[xn] + rf[xn];
-  return (3 * cs + cn + ((x & 1) ? 7 : 8)) >> 4;
+__device__ __forceinline__ uint32_t ycc_l(int Y, int cb, int cr) {
+  cb -= 128;
+  cr -= 128;
+  const int R = min(max(Y + ((91881 * cr + 32768) >> 16), 0), 255);
+  const int G = min(max(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0), 255);
+  const int B = min(max(Y + ((116130 * cb + 32768) >> 16), 0), 255);
+  return (uint32_t)((R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16);
 }
 
+// Thread = four pixels of a row (x0 a multiple of 4).  Plane strides are multiples of 16 bytes (dword loads).
 __global__ __launch_bounds__(256) void ycc_to_l_kernel(const uint8_t* __restrict__ py, ptrdiff_t sy,
                                                        const uint8_t* __restrict__ pcb, const uint8_t* __restrict__ pcr,
                                                        ptrdiff_t sc, int cw, int ch, int h0, int v0, int H, int W,
                                                        uint8_t* __restrict__ out, ptrdiff_t so) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= W || y >= H) return;
-  const int Y = py[(ptrdiff_t)y * sy + x];
-  const int cb = chroma_at(pcb, sc, cw, ch, h0, v0, x, y) - 128;
-  const int cr = chroma_at(pcr, sc, cw, ch, h0, v0, x, y) - 128;
-  const int R = min(max(Y + ((91881 * cr + 32768) >> 16), 0), 255);
-  const int G = min(max(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0), 255);
-  const int B = min(max(Y + ((116130 * cb + 32768) >> 16), 0), 255);
-  out[(ptrdiff_t)y * so + x] = (uint8_t)((R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16);
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+  if (x0 >= W || y >= H) return;
+  const uint32_t yy = *reinterpret_cast<const uint32_t*>(py + (ptrdiff_t)y * sy + x0);
+  int cb[4], cr[4];
+  if (h0 == 1) {
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(pcb + (ptrdiff_t)y * sc + x0);
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(pcr + (ptrdiff_t)y * sc + x0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cb[j] = (int)((b >> (8 * j)) & 255u);
+      cr[j] = (int)((r >> (8 * j)) & 255u);
+    }
+  } else {
+    // chroma columns xc - 1 ... xc + 2 serve the four pixels (edge columns repeat)
+    const int xc = x0 >> 1;
+    const int xi[4] = {max(xc - 1, 0), xc, min(xc + 1, cw - 1), min(xc + 2, cw - 1)};
+    const int yc = v0 == 2 ? y >> 1 : y;
+    const int yf = v0 == 2 ? min(max(yc + ((y & 1) ? 1 : -1), 0), ch - 1) : yc;
+    const uint8_t* const planes[2] = {pcb, pcr};
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const uint8_t* rn = planes[pi] + (ptrdiff_t)yc * sc;
+      const uint8_t* rf = planes[pi] + (ptrdiff_t)yf * sc;
+      int cs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cs[j] = v0 == 2 ? 3 * rn[xi[j]] + rf[xi[j]] : rn[xi[j]];
+      int* o = pi == 0 ? cb : cr;
+      if (v0 == 2) {
+        o[0] = (3 * cs[1] + cs[0] + 8) >> 4;
+        o[1] = (3 * cs[1] + cs[2] + 7) >> 4;
+        o[2] = (3 * cs[2] + cs[1] + 8) >> 4;
+        o[3] = (3 * cs[2] + cs[3] + 7) >> 4;
+      } else {
+        o[0] = (3 * cs[1] + cs[0] + 1) >> 2;
+        o[1] = (3 * cs[1] + cs[2] + 2) >> 2;
+        o[2] = (3 * cs[2] + cs[1] + 1) >> 2;
+        o[3] = (3 * cs[2] + cs[3] + 2) >> 2;
+      }
+    }
+  }
+  uint32_t l = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) l |= ycc_l((int)((yy >> (8 * j)) & 255u), cb[j], cr[j]) << (8 * j);
+  uint8_t* o = out + (ptrdiff_t)y * so + x0;
+  if (x0 + 4 <= W && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+    *reinterpret_cast<uint32_t*>(o) = l;
+  } else {
+    for (int j = 0; j < 4 && x0 + j < W; ++j) o[j] = (uint8_t)((l >> (8 * j)) & 255u);
+  }
 }
 
 // ---- host: file structure --------------------------------------------------------------------------------
@@ -472,6 +595,8 @@ struct JpegInfo {
   bool supported = false;
   const char* why = "";
   size_t scan_begin = 0, scan_end = 0;
+  int restart = 0;            // MCUs per restart interval, 0: none
+  std::vector<uint64_t> rst;  // offsets (from scan_begin) of the first byte behind each RSTn marker
   DecTables tabs;
 };
 
@@ -491,6 +616,7 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   int tq[3] = {-1, -1, -1}, td[3] = {-1, -1, -1}, ta[3] = {-1, -1, -1}, comp_id[3] = {-1, -1, -1};
   int hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
   bool have_sof = false, have_jfif = false;
+  int restart = 0;  // MCUs per restart interval (DRI), 0: none
   size_t p = 2;
   while (true) {
     OGD_REQUIRE(p + 4 <= n, "truncated JPEG file");
@@ -567,7 +693,7 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
       JP_UNSUP("not a baseline / sequential Huffman file");
     } else if (m == 0xDD) {
       OGD_REQUIRE(sl >= 2, "truncated DRI segment");
-      if (((s[0] << 8) | s[1]) != 0) JP_UNSUP("restart intervals");
+      restart = (s[0] << 8) | s[1];
     } else if (m == 0xE0) {
       if (sl >= 5 && std::memcmp(s, "JFIF", 5) == 0) have_jfif = true;
     } else if (m == 0xEE) {
@@ -603,11 +729,18 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
       e += 2;
       continue;
     }
+    if (restart > 0 && f[e + 1] >= 0xD0 && f[e + 1] <= 0xD7) {  // RSTn: the next interval begins behind it
+      if ((int)(f[e + 1] - 0xD0) != (int)(info.rst.size() & 7)) JP_UNSUP("restart markers out of order");
+      e += 2;
+      info.rst.push_back((uint64_t)(e - p));
+      continue;
+    }
     break;
   }
-  if (f[e + 1] != 0xD9) JP_UNSUP("marker inside the scan");  // RSTn, further scans, fill bytes
+  if (f[e + 1] != 0xD9) JP_UNSUP("marker inside the scan");  // RSTn without DRI, further scans, fill bytes
   info.scan_begin = p;
   info.scan_end = e;
+  info.restart = restart;
   DecTables& T = info.tabs;
   std::memset(&T, 0, sizeof T);
   // at most two DC and two AC tables in use (baseline)
@@ -641,6 +774,14 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   T.base[1] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0) : 0;
   T.base[2] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0 + nmcu) : 0;
   T.ntot = (int32_t)(nmcu * T.bpm);
+  if (restart > 0) {
+    const int64_t nint = (nmcu + restart - 1) / restart;
+    if ((int64_t)info.rst.size() + 1 != nint) JP_UNSUP("number of restart markers does not match the image");
+    // an interval is one lane's work (decode_intervals_kernel): a few long intervals would be slower than libjpeg
+    if (nint < 64 && nmcu * T.bpm > 65536) JP_UNSUP("restart intervals too long to be worth a lane each");
+  } else if (!info.rst.empty()) {
+    JP_UNSUP("restart markers without a restart interval");
+  }
   info.supported = true;
   return OGD_OK;
 }
@@ -653,6 +794,89 @@ static int scan_u64(DevBuf& tmp, uint64_t* d, int count, hipStream_t st) {
   return OGD_OK;
 }
 
+// D6 (+ D7): coefficients and DC values of all blocks -> the "L" image
+static int blocks_to_image(const JpegInfo& info, const DevBuf& dcoef, const DevBuf& ddc, const DecTables* tabs,
+                           uint8_t* d_img, ptrdiff_t stride, hipStream_t st) {
+  const int H = info.H, W = info.W;
+  const int mcux = (W + 8 * info.h0 - 1) / (8 * info.h0);
+  const int64_t nblk = info.tabs.ntot;
+  const dim3 blk(256);
+  DevBuf dplanes;
+  Planes pl;
+  std::memset(&pl, 0, sizeof pl);
+  pl.mcux = mcux;
+  pl.h0 = info.h0;
+  pl.v0 = info.v0;
+  const int cw = (W + info.h0 - 1) / info.h0, ch = (H + info.v0 - 1) / info.v0;  // libjpeg's downsampled size
+  if (info.ncomp == 1) {
+    pl.p[0] = d_img;
+    pl.stride[0] = stride;
+    pl.W[0] = W;
+    pl.H[0] = H;
+  } else {
+    const size_t ys = ((size_t)W + 15) & ~(size_t)15, cs = ((size_t)cw + 15) & ~(size_t)15;  // ycc_to_l_kernel loads dwords
+    const size_t ysz = ys * H, csz = cs * ch;
+    OGD_TRY(dplanes.alloc(ysz + 2 * csz));
+    pl.p[0] = dplanes.as<uint8_t>();
+    pl.p[1] = pl.p[0] + ysz;
+    pl.p[2] = pl.p[1] + csz;
+    pl.stride[0] = (ptrdiff_t)ys;
+    pl.stride[1] = pl.stride[2] = (ptrdiff_t)cs;
+    pl.W[0] = W;
+    pl.H[0] = H;
+    pl.W[1] = pl.W[2] = cw;
+    pl.H[1] = pl.H[2] = ch;
+  }
+  hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), blk, 0, st, dcoef.as<uint4>(), ddc.as<int32_t>(),
+                     tabs, pl);
+  OGD_TRY(check_launch("idct_kernel"));
+  if (info.ncomp == 3) {
+    OGD_REQUIRE(H <= 65535, "image too tall");
+    hipLaunchKernelGGL(ycc_to_l_kernel, dim3((unsigned)((W + 1023) / 1024), (unsigned)H), blk, 0, st, pl.p[0], pl.stride[0],
+                       pl.p[1], pl.p[2], pl.stride[1], cw, ch, info.h0, info.v0, H, W, d_img, stride);
+    OGD_TRY(check_launch("ycc_to_l_kernel"));
+  }
+  OGD_HIP(hipStreamSynchronize(st));  // dplanes goes back to the block cache on return
+  return OGD_OK;
+}
+
+// Scans with restart intervals: upload, one lane per interval, then as above.
+static int decode_intervals_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride,
+                                      hipStream_t st) {
+  const int mcux = (info.W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (info.H + 8 * info.v0 - 1) / (8 * info.v0);
+  const int64_t nmcu = (int64_t)mcux * mcuy;
+  const int64_t nblk = info.tabs.ntot;
+  const uint64_t nscan = info.scan_end - info.scan_begin;
+  OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
+  const int nint = (int)info.rst.size() + 1;
+  std::vector<uint64_t> starts((size_t)nint + 1);
+  starts[0] = 0;
+  for (int j = 1; j < nint; ++j) starts[j] = info.rst[j - 1];
+  starts[nint] = nscan;
+  DevBuf draw, dstarts, dtabs, dflag, dcoef, ddc;
+  OGD_TRY(draw.alloc((size_t)nscan + 16));
+  OGD_TRY(dstarts.alloc(starts.size() * sizeof(uint64_t)));
+  OGD_TRY(dtabs.alloc(sizeof(DecTables)));
+  OGD_TRY(dflag.alloc(16));
+  OGD_TRY(dcoef.alloc((size_t)nblk * 64 * sizeof(int16_t)));
+  OGD_TRY(ddc.alloc((size_t)nblk * sizeof(int32_t)));
+  OGD_HIP(hipMemcpyAsync(draw.p, file + info.scan_begin, (size_t)nscan, hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemcpyAsync(dstarts.p, starts.data(), starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemcpyAsync(dtabs.p, &info.tabs, sizeof(DecTables), hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
+  OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
+  const DecTables* tabs = dtabs.as<DecTables>();
+  hipLaunchKernelGGL(decode_intervals_kernel, dim3((unsigned)((nint + 63) / 64)), dim3(64), 0, st, draw.as<uint8_t>(),
+                     dstarts.as<uint64_t>(), nint, tabs, info.restart, nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(),
+                     dflag.as<int>());
+  OGD_TRY(check_launch("decode_intervals_kernel"));
+  int cut_short = 0;
+  OGD_HIP(hipMemcpyAsync(&cut_short, dflag.p, sizeof cut_short, hipMemcpyDeviceToHost, st));
+  OGD_HIP(hipStreamSynchronize(st));  // also: `starts` and the tables have been read
+  if (cut_short) return fail(OGD_ERR_RUNTIME, "a restart interval of the JPEG scan ends before its blocks do");
+  return blocks_to_image(info, dcoef, ddc, tabs, d_img, stride, st);
+}
+
 static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride, hipStream_t st) {
   const int H = info.H, W = info.W;
   const int mcux = (W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (H + 8 * info.v0 - 1) / (8 * info.v0);
@@ -660,6 +884,8 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   const int64_t nblk = info.tabs.ntot;  // coefficient slots = blocks of all components
   const uint64_t nscan = info.scan_end - info.scan_begin;
   OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
+
+  if (info.restart > 0) return decode_intervals_to_device(file, info, d_img, stride, st);
 
   // D1
   const int64_t nun64 = (int64_t)((nscan + UN_CHUNK - 1) / UN_CHUNK);
@@ -699,10 +925,13 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
                      dnb.as<uint64_t>());
   OGD_TRY(check_launch("init_states_kernel"));
   const DecTables* tabs = dtabs.as<DecTables>();
+  const bool multi = info.tabs.bpm > 1;
+  const auto state_pass = multi ? &decode_chunks_kernel<false, true> : &decode_chunks_kernel<false, false>;
+  const auto write_pass = multi ? &decode_chunks_kernel<true, true> : &decode_chunks_kernel<true, false>;
   int rounds = 0;
   while (true) {
     OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
-    hipLaunchKernelGGL(decode_chunks_kernel<false>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
+    hipLaunchKernelGGL(state_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
                        (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
                        rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)));
@@ -736,12 +965,11 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_TRY(dcoef.alloc((size_t)nblk * 64 * sizeof(int16_t)));
   OGD_TRY(ddc.alloc((size_t)nblk * sizeof(int32_t)));
   OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
-  hipLaunchKernelGGL(decode_chunks_kernel<true>, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
+  hipLaunchKernelGGL(write_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
                      dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0);
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
   // D5: DC prediction runs per component, in stream order: one inclusive scan per component's slots
-  DevBuf dplanes;
   {
     const int ncomp = info.ncomp;
     const int32_t starts[4] = {info.tabs.base[0], ncomp == 3 ? info.tabs.base[1] : (int32_t)nblk,
@@ -755,40 +983,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
       OGD_HIP(hipcub::DeviceScan::InclusiveSum(dtmp3.p, sbc, ddc.as<int32_t>() + starts[c], ddc.as<int32_t>() + starts[c], cnt, st));
     }
   }
-  // D6 (+ D7)
-  Planes pl;
-  std::memset(&pl, 0, sizeof pl);
-  pl.mcux = mcux;
-  pl.h0 = info.h0;
-  pl.v0 = info.v0;
-  const int cw = (W + info.h0 - 1) / info.h0, ch = (H + info.v0 - 1) / info.v0;  // libjpeg's downsampled size
-  if (info.ncomp == 1) {
-    pl.p[0] = d_img;
-    pl.stride[0] = stride;
-    pl.W[0] = W;
-    pl.H[0] = H;
-  } else {
-    const size_t ysz = (size_t)W * H, csz = (size_t)cw * ch;
-    OGD_TRY(dplanes.alloc(ysz + 2 * csz));
-    pl.p[0] = dplanes.as<uint8_t>();
-    pl.p[1] = pl.p[0] + ysz;
-    pl.p[2] = pl.p[1] + csz;
-    pl.stride[0] = W;
-    pl.stride[1] = pl.stride[2] = cw;
-    pl.W[0] = W;
-    pl.H[0] = H;
-    pl.W[1] = pl.W[2] = cw;
-    pl.H[1] = pl.H[2] = ch;
-  }
-  hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), blk, 0, st, dcoef.as<uint4>(), ddc.as<int32_t>(),
-                     tabs, pl);
-  OGD_TRY(check_launch("idct_kernel"));
-  if (info.ncomp == 3) {
-    OGD_REQUIRE(H <= 65535, "image too tall");
-    hipLaunchKernelGGL(ycc_to_l_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), blk, 0, st, pl.p[0], pl.stride[0],
-                       pl.p[1], pl.p[2], pl.stride[1], cw, ch, info.h0, info.v0, H, W, d_img, stride);
-    OGD_TRY(check_launch("ycc_to_l_kernel"));
-  }
+  OGD_TRY(blocks_to_image(info, dcoef, ddc, tabs, d_img, stride, st));
   OGD_HIP(hipStreamSynchronize(st));  // the scratch buffers go back to the block cache on return
   return OGD_OK;
 }

@@ -224,3 +224,17 @@ def write_reliable_stage(page_path, rng, nodes, cell, n_lines=30, n_table_lines=
 				tesseract_data=dict(baseline=[p, [p[0] + right[0], p[1] + right[1]]], descent=4, ascent=12, height=20))))
 	(out / "tables.json").write_text(json.dumps(dict(version=1, columns=columns, dividers={})))
 	return lines
+
+
+def colour_page(rng, size):
+	"""A scan in colour, (H, W, 3) uint8: yellowed paper, dark text, a coloured stamp, sensor noise."""
+	W, H = size
+	text = text_page(rng, size).astype(np.float32) * (1.0 / 255.0)
+	paper = np.array([236, 222, 190], np.float32)
+	ink = np.array([40, 32, 36], np.float32)
+	rgb = ink + (paper - ink) * text[:, :, None]
+	yy, xx = np.ogrid[0:H, 0:W]
+	stamp = ((yy - H // 3) ** 2 + (xx - W // 2) ** 2) < (min(W, H) // 6) ** 2
+	rgb[stamp] = 0.5 * rgb[stamp] + 0.5 * np.array([200, 30, 40], np.float32)
+	rgb += rng.normal(0, 3, size=rgb.shape).astype(np.float32)
+	return np.clip(rgb, 0, 255).astype(np.uint8)

@@ -95,18 +95,7 @@ def _check_colour(gpu, rgb, **params):
 		(got != want).sum(), np.abs(got.astype(int) - want).max())
 
 
-def _colour_page(rng, size):
-	"""A scan in colour: yellowed paper, dark text, a coloured stamp, sensor noise."""
-	W, H = size
-	text = synth.text_page(rng, size).astype(np.float32) / 255.0
-	paper = np.array([236, 222, 190], np.float32)
-	ink = np.array([40, 32, 36], np.float32)
-	rgb = ink + (paper - ink) * text[:, :, None]
-	yy, xx = np.mgrid[0:H, 0:W]
-	stamp = ((yy - H // 3) ** 2 + (xx - W // 2) ** 2) < (min(W, H) // 6) ** 2
-	rgb[stamp] = 0.5 * rgb[stamp] + 0.5 * np.array([200, 30, 40], np.float32)
-	rgb += rng.normal(0, 3, size=rgb.shape)
-	return np.clip(rgb, 0, 255).astype(np.uint8)
+_colour_page = synth.colour_page
 
 
 @pytest.mark.parametrize("subsampling", [0, 1, 2])
@@ -148,6 +137,76 @@ def test_colour_scan_file_to_dewarped_file_on_the_device(gpu):
 	nodes = synth.Warp.random(rng, size).node_grid(25)
 	want = ojpeg.save_gray(gpu.dewarp_u8(_pil_decode(scan), nodes, 25))
 	assert gpu.jpeg_dewarp_jpeg_gray(scan, nodes, 25) == want
+
+
+def _restart_file(pixels, **params):
+	buf = io.BytesIO()
+	PIL.Image.fromarray(pixels).save(buf, format="JPEG", **params)
+	data = buf.getvalue()
+	assert b"\xff\xdd" in data  # a DRI segment
+	return data
+
+
+def _check_file(gpu, data):
+	got = gpu.jpeg_decode_gray(data)
+	assert got is not None, "decoder refused the file: %s" % (gpu.jpeg_info(data),)
+	want = _pil_decode(data)
+	assert got.shape == want.shape
+	assert np.array_equal(got, want), "%d pixels differ, max %d" % (
+		(got != want).sum(), np.abs(got.astype(int) - want).max())
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (17, 33), (250, 301), (640, 999)])
+@pytest.mark.parametrize("restart", [dict(restart_marker_rows=1), dict(restart_marker_blocks=1),
+	dict(restart_marker_blocks=3), dict(restart_marker_blocks=17), dict(restart_marker_rows=4)])
+def test_scans_with_restart_intervals(gpu, shape, restart):
+	"""DRI: every interval is byte-aligned and starts its DC predictions anew; more than eight markers (RST0-7 cycle)."""
+	rng = np.random.default_rng(shape[0] + shape[1])
+	_check_file(gpu, _restart_file(rng.integers(0, 256, size=shape, dtype=np.uint8), quality=90, **restart))
+	rgb = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+	for sub in (0, 1, 2):
+		_check_file(gpu, _restart_file(rgb, quality=80, subsampling=sub, **restart))
+
+
+def test_restart_intervals_text_pages_and_fitted_tables(gpu):
+	rng = np.random.default_rng(21)
+	_check_file(gpu, _restart_file(synth.text_page(rng, (1500, 2000)), restart_marker_rows=1))
+	_check_file(gpu, _restart_file(synth.text_page(rng, (1500, 2000)), restart_marker_rows=2, optimize=True, quality=95))
+	_check_file(gpu, _restart_file(synth.colour_page(rng, (1100, 1500)), restart_marker_rows=1, quality=85))
+	_check_file(gpu, _restart_file(np.full((300, 200), 255, np.uint8), restart_marker_blocks=5))  # all-ones bytes: stuffing
+
+
+def test_restart_intervals_whole_broadsheet_scan(gpu):
+	rng = np.random.default_rng(22)
+	_check_file(gpu, _restart_file(synth.text_page(rng, (6000, 8000)), restart_marker_rows=1))
+
+
+def test_restart_intervals_damaged_or_too_long(gpu):
+	rng = np.random.default_rng(23)
+	page = synth.text_page(rng, (512, 384))
+	data = bytearray(_restart_file(page, restart_marker_rows=1))
+	# a marker removed: the count no longer matches -> handed back
+	pos = data.index(b"\xff\xd3")
+	assert gpu.jpeg_decode_gray(bytes(data[:pos] + data[pos + 2:])) is None
+	# markers out of order -> handed back
+	swapped = bytearray(data)
+	swapped[pos + 1] = 0xD5
+	assert gpu.jpeg_decode_gray(bytes(swapped)) is None
+	# an interval cut short (bytes removed in front of a marker) -> handed back, no fault
+	assert gpu.jpeg_decode_gray(bytes(data[:pos - 40] + data[pos:])) is None
+	# random damage inside intervals: an image or None, never a fault
+	start = data.index(b"\xff\xda") + 10
+	for trial in range(8):
+		bad = bytearray(data)
+		for q in rng.integers(start, len(bad) - 2, size=4 + trial * 8):
+			if bad[q] != 0xFF and bad[q - 1] != 0xFF:
+				bad[q] = int(rng.integers(0, 255))
+		out = gpu.jpeg_decode_gray(bytes(bad))
+		assert out is None or out.shape == (384, 512)
+	# one interval for a whole large scan: a single lane would decode it -> left to PIL
+	big = _restart_file(synth.text_page(rng, (2400, 3400)), restart_marker_rows=500)
+	assert gpu.jpeg_info(big)[3] is False
+	_check_file(gpu, bytes(data))
 
 
 def test_truncated_scan_is_left_to_pil(gpu):

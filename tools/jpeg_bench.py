@@ -90,3 +90,47 @@ dt, _ = timed(lambda: _shim.check(lib.ogd_jpeg_decode_gray_dev(buf.ctypes.data, 
 print("ogd_jpeg_decode_gray_dev (pixels stay on the device): %5.1f ms = %7.0f MP/s" % (dt * 1e3, H * W / 1e6 / dt))
 _shim.check(lib.ogd_dev_free(d_px))
 print("decoded pixels identical to PIL's")
+
+# ---- the same scan in colour (JFIF YCbCr; the reference converts it to "L" on opening) ----
+rgb = synth.colour_page(rng, (W, H))
+for name, params in (("4:2:0", dict(subsampling=2)), ("4:4:4", dict(subsampling=0))):
+	b = io.BytesIO()
+	PIL.Image.fromarray(rgb).save(b, format="JPEG", quality=85, **params)
+	cscan = b.getvalue()
+	t0 = time.perf_counter()
+	want_px = np.array(PIL.Image.open(io.BytesIO(cscan)).convert("L"))
+	t_pil = time.perf_counter() - t0
+	print("colour scan %dx%d %s as a JPEG file of %d bytes" % (W, H, name, len(cscan)))
+	print("  PIL decode + convert('L'), 1 host thread:  %8.1f ms = %7.0f MP/s" % (t_pil * 1e3, H * W / 1e6 / t_pil))
+	dt, got_px = timed(lambda: _shim.jpeg_decode_gray(cscan))
+	assert np.array_equal(got_px, want_px)
+	print("  ogd_jpeg_decode_gray (file in, host pixels): %7.1f ms = %7.0f MP/s" % (dt * 1e3, H * W / 1e6 / dt))
+	cbuf = np.frombuffer(cscan, np.uint8)
+	d_px = ctypes.c_void_p()
+	_shim.check(lib.ogd_dev_alloc(ctypes.byref(d_px), H * W))
+	dt, _ = timed(lambda: _shim.check(lib.ogd_jpeg_decode_gray_dev(cbuf.ctypes.data, cbuf.size, d_px, H, W, W, None)))
+	print("  ogd_jpeg_decode_gray_dev (pixels stay on the device): %5.1f ms = %7.0f MP/s" % (dt * 1e3, H * W / 1e6 / dt))
+	_shim.check(lib.ogd_dev_free(d_px))
+print("colour scans: 'L' pixels identical to PIL's")
+
+# ---- scans with restart intervals (DRI): one lane per interval ----
+for name, img, params in (("gray, restart every MCU row", page, dict(restart_marker_rows=1)),
+		("4:2:0 colour, restart every MCU row", rgb, dict(restart_marker_rows=1, quality=85, subsampling=2))):
+	b = io.BytesIO()
+	PIL.Image.fromarray(img).save(b, format="JPEG", **params)
+	rscan = b.getvalue()
+	t0 = time.perf_counter()
+	want_px = np.array(PIL.Image.open(io.BytesIO(rscan)).convert("L"))
+	t_pil = time.perf_counter() - t0
+	print("scan %dx%d, %s: %d bytes" % (W, H, name, len(rscan)))
+	print("  PIL decode, 1 host thread:                 %8.1f ms" % (t_pil * 1e3))
+	dt, got_px = timed(lambda: _shim.jpeg_decode_gray(rscan))
+	assert np.array_equal(got_px, want_px)
+	print("  ogd_jpeg_decode_gray (file in, host pixels): %7.1f ms" % (dt * 1e3))
+	rbuf = np.frombuffer(rscan, np.uint8)
+	d_px = ctypes.c_void_p()
+	_shim.check(lib.ogd_dev_alloc(ctypes.byref(d_px), H * W))
+	dt, _ = timed(lambda: _shim.check(lib.ogd_jpeg_decode_gray_dev(rbuf.ctypes.data, rbuf.size, d_px, H, W, W, None)))
+	print("  ogd_jpeg_decode_gray_dev (pixels stay on the device): %5.1f ms" % (dt * 1e3))
+	_shim.check(lib.ogd_dev_free(d_px))
+print("restart-interval scans: pixels identical to PIL's")
