@@ -290,7 +290,9 @@ __global__ __launch_bounds__(64) void decode_intervals_kernel(const uint8_t* __r
   uint64_t pos = starts[j];
   const uint64_t end = starts[j + 1];  // the next interval's first byte (its marker lies in between: never read as data)
   const uint64_t data_end = j + 1 < nint ? end - 2 : end;
-  uint64_t acc = 0;
+  typedef uint32_t u32u __attribute__((aligned(1)));
+  uint64_t acc = 0, pre_pos = ~0ull;
+  uint32_t pre = 0;
   int nbits = 0, over = 0;
   int pred[3] = {0, 0, 0};
   const size_t ntot = (size_t)t.ntot;
@@ -303,16 +305,32 @@ __global__ __launch_bounds__(64) void decode_intervals_kernel(const uint8_t* __r
       const DecHuff& ha = t.ac[t.ac_sel[comp]];
       int k = 0;
       while (k < 64) {
-        while (nbits <= 56) {  // refill: a symbol takes at most 16 + 15 bits
-          uint32_t b = 0;
-          if (pos < data_end) {
-            b = raw[pos++];
-            if (b == 0xFFu && pos < data_end && raw[pos] == 0) ++pos;
-          } else {
-            ++over;
+        if (nbits <= 32) {  // refill: a symbol takes at most 16 + 15 bits
+          // four bytes at once while none of them is 0xFF (stuffing, or the next marker); the word behind them
+          // is requested right away, several symbols before it is needed
+          bool fast = false;
+          if (pos + 4 <= data_end) {
+            const uint32_t x = pre_pos == pos ? pre : *reinterpret_cast<const u32u*>(raw + pos);
+            if (((~x - 0x01010101u) & x & 0x80808080u) == 0) {
+              acc |= (uint64_t)__builtin_bswap32(x) << (32 - nbits);
+              nbits += 32;
+              pos += 4;
+              pre_pos = pos;
+              pre = *reinterpret_cast<const u32u*>(raw + pos);  // the buffer is padded
+              fast = true;
+            }
           }
-          acc |= (uint64_t)b << (56 - nbits);
-          nbits += 8;
+          while (!fast && nbits <= 56) {
+            uint32_t b = 0;
+            if (pos < data_end) {
+              b = raw[pos++];
+              if (b == 0xFFu && pos < data_end && raw[pos] == 0) ++pos;
+            } else {
+              ++over;
+            }
+            acc |= (uint64_t)b << (56 - nbits);
+            nbits += 8;
+          }
         }
         int len;
         if (k == 0) {
@@ -777,8 +795,10 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   if (restart > 0) {
     const int64_t nint = (nmcu + restart - 1) / restart;
     if ((int64_t)info.rst.size() + 1 != nint) JP_UNSUP("number of restart markers does not match the image");
-    // an interval is one lane's work (decode_intervals_kernel): a few long intervals would be slower than libjpeg
-    if (nint < 64 && nmcu * T.bpm > 65536) JP_UNSUP("restart intervals too long to be worth a lane each");
+    // an interval is one lane's work (decode_intervals_kernel, ~25 us per block against libjpeg's ~0.1 us on a
+    // host core): only worth it with some hundred intervals, or when the whole scan is small
+    const int64_t per_lane = (int64_t)restart * T.bpm, all = nmcu * T.bpm;
+    if (per_lane > std::max<int64_t>(1024, all / 256)) JP_UNSUP("restart intervals too long to be worth a lane each");
   } else if (!info.rst.empty()) {
     JP_UNSUP("restart markers without a restart interval");
   }

@@ -158,7 +158,7 @@ def _check_file(gpu, data):
 
 @pytest.mark.parametrize("shape", [(8, 8), (17, 33), (250, 301), (640, 999)])
 @pytest.mark.parametrize("restart", [dict(restart_marker_rows=1), dict(restart_marker_blocks=1),
-	dict(restart_marker_blocks=3), dict(restart_marker_blocks=17), dict(restart_marker_rows=4)])
+	dict(restart_marker_blocks=3), dict(restart_marker_blocks=17), dict(restart_marker_rows=2)])
 def test_scans_with_restart_intervals(gpu, shape, restart):
 	"""DRI: every interval is byte-aligned and starts its DC predictions anew; more than eight markers (RST0-7 cycle)."""
 	rng = np.random.default_rng(shape[0] + shape[1])
