@@ -75,8 +75,13 @@ static bool build_dec_huff(const uint8_t* bits, const uint8_t* vals, int nvals, 
 
 // ---- D1 ------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool is_stuffing(const uint8_t* __restrict__ raw, uint64_t i) {
-  return i > 0 && raw[i] == 0 && raw[i - 1] == 0xFF;
+// Bytes that are not entropy-coded data: the 0x00 stuffed behind a 0xFF data byte, and both bytes of an RSTn
+// marker (in the raw segment 0xFF is followed by 0x00 or, in files with restart intervals, by 0xD0 - 0xD7 only:
+// the host has checked that).
+__device__ __forceinline__ bool is_stuffing(const uint8_t* __restrict__ raw, uint64_t i, uint64_t n) {
+  const uint32_t b = raw[i];
+  if (i > 0 && raw[i - 1] == 0xFF && (b == 0 || (b & 0xF8u) == 0xD0u)) return true;
+  return b == 0xFFu && i + 1 < n && (raw[i + 1] & 0xF8u) == 0xD0u;
 }
 
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ raw, uint64_t n, int nchunk,
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __res
   if (ch < nchunk) {
     const uint64_t i0 = (uint64_t)ch * UN_CHUNK + threadIdx.x * 16;
     for (int k = 0; k < 16; ++k)
-      if (i0 + k < n) c += is_stuffing(raw, i0 + k);
+      if (i0 + k < n) c += is_stuffing(raw, i0 + k, n);
   }
   const int total = Reduce(tmp).Sum(c);
   if (threadIdx.x == 0) counts[ch] = ch < nchunk ? (uint64_t)total : 0;  // counts[nchunk]: sentinel
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __r
   int c = 0;
   uint32_t drop = 0;
   for (int k = 0; k < 16; ++k)
-    if (i0 + k < n && is_stuffing(raw, i0 + k)) {
+    if (i0 + k < n && is_stuffing(raw, i0 + k, n)) {
       drop |= 1u << k;
       ++c;
     }
@@ -154,7 +159,11 @@ struct ChunkState {
 // Walks chunk `i` from the exit state of chunk i - 1.  WRITE = false: publishes the exit state (and whether it
 // changed) and the number of blocks completed.  WRITE = true: stores the coefficients.  MULTI = false: one
 // component, one block per MCU, one pair of tables (the usual scan: no per-block table look-ups).
-template <bool WRITE, bool MULTI>
+// RST = true: the scan has restart intervals; `rst_bits` lists the bit positions at which intervals 1, 2, ... begin
+// in the compacted stream.  After an MCU whose end lies less than 8 bits, all of them 1, in front of such a position
+// the walk continues there with a fresh block (no code word is all ones, so those bits cannot be another MCU).
+// The write pass counts the restarts it takes and checks that each comes after exactly `restart` MCUs.
+template <bool WRITE, bool MULTI, bool RST>
 __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __restrict__ s, uint64_t total_bits,
                                                             int nchunk, const DecTables* __restrict__ tabs,
                                                             const ChunkState* __restrict__ entry,  // [nchunk]: exit of i - 1
@@ -162,7 +171,8 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
                                                             uint64_t* __restrict__ nblocks, int* __restrict__ changed,
                                                             const uint64_t* __restrict__ first_block, int64_t nmcu,
                                                             int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff,
-                                                            int forward) {
+                                                            int forward, const uint64_t* __restrict__ rst_bits, int nrst,
+                                                            int restart, int* __restrict__ rst_check) {
   __shared__ DecTables t;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
@@ -181,6 +191,19 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   int64_t mcu = WRITE ? (MULTI ? (int64_t)(first_block[i] / (uint64_t)t.bpm) : (int64_t)first_block[i]) : 0;
   const size_t ntot = (size_t)t.ntot;
   int c = i;  // the chunk being walked (a state pass may carry on into the following ones, see below)
+  int ri = 0;                 // the next interval start behind p (a state at an MCU border has taken the restart at p)
+  uint64_t next_rst = ~0ull;  // its bit position
+  int taken = 0;              // write pass: restarts taken on this walk, and whether one came after the wrong number of MCUs
+  bool misplaced = false;
+  if (RST) {
+    int lo = 0, hi = nrst;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rst_bits[mid] <= p) lo = mid + 1; else hi = mid;
+    }
+    ri = lo;
+    if (ri < nrst) next_rst = rst_bits[ri];
+  }
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
   uint64_t p0 = p, w0 = window(s, p);
 walk:
@@ -237,8 +260,30 @@ walk:
           m = 0;
           ++mcu;
         }
+        if (RST && m == 0) {
+          while (next_rst < p) {  // passed without a restart: this walk is on a wrong parse
+            ++ri;
+            next_rst = ri < nrst ? rst_bits[ri] : ~0ull;
+          }
+          const uint64_t pad = next_rst - p;
+          if (pad < 8 && (pad == 0 || (window(s, p) >> (64 - pad)) == (1ull << pad) - 1)) {
+            if (WRITE) {
+              ++taken;
+              if (mcu != (int64_t)(ri + 1) * restart) misplaced = true;
+            }
+            p = next_rst;
+            ++ri;
+            next_rst = ri < nrst ? rst_bits[ri] : ~0ull;
+          }
+        }
       }
     }
+  }
+  // (one atomic per walk, here: an atomicAdd inside the divergent decode loop above made neighbouring lanes store
+  // wrong coefficient values in launches of more than 65536 chunks — measured, not understood; gfx950, ROCm 7.2)
+  if (WRITE && RST) {
+    if (taken) atomicAdd(rst_check, taken);
+    if (misplaced) rst_check[1] = 1;
   }
   if (!WRITE) {
     const ChunkState old = exit_state[c];
@@ -269,106 +314,16 @@ walk:
 }
 
 
-// ---- D2' : scans with restart intervals ----------------------------------------------------------------
-// An RSTn marker byte-aligns the stream and resets the DC predictions (T.81 F.2.1.3.1 / libjpeg's
-// process_restart): every interval decodes on its own and knows its first MCU, so no chunk iteration is needed.
-// Thread = interval, reading the raw segment (stuffing still in place) byte by byte; DC values are accumulated
-// here (absolute values go to `dc`, no scan).  An interval whose data ends before its MCUs do sets *short_flag.
-__global__ __launch_bounds__(64) void decode_intervals_kernel(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ starts,
-                                                              int nint, const DecTables* __restrict__ tabs, int restart,
-                                                              int64_t nmcu, int16_t* __restrict__ coef,
-                                                              int32_t* __restrict__ dc, int* __restrict__ short_flag) {
-  __shared__ DecTables t;
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
-    for (int i = threadIdx.x; i < (int)(sizeof(DecTables) / 4); i += 64) dst[i] = src[i];
-    __syncthreads();
-  }
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  if (j >= nint) return;
-  uint64_t pos = starts[j];
-  const uint64_t end = starts[j + 1];  // the next interval's first byte (its marker lies in between: never read as data)
-  const uint64_t data_end = j + 1 < nint ? end - 2 : end;
-  typedef uint32_t u32u __attribute__((aligned(1)));
-  uint64_t acc = 0, pre_pos = ~0ull;
-  uint32_t pre = 0;
-  int nbits = 0, over = 0;
-  int pred[3] = {0, 0, 0};
-  const size_t ntot = (size_t)t.ntot;
-  const int64_t mcu_end = min((int64_t)(j + 1) * restart, nmcu);
-  for (int64_t mcu = (int64_t)j * restart; mcu < mcu_end; ++mcu) {
-    for (int m = 0; m < t.bpm; ++m) {
-      const int comp = t.blk_comp[m];
-      const size_t slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
-      const DecHuff& hd = t.dc[t.dc_sel[comp]];
-      const DecHuff& ha = t.ac[t.ac_sel[comp]];
-      int k = 0;
-      while (k < 64) {
-        if (nbits <= 32) {  // refill: a symbol takes at most 16 + 15 bits
-          // four bytes at once while none of them is 0xFF (stuffing, or the next marker); the word behind them
-          // is requested right away, several symbols before it is needed
-          bool fast = false;
-          if (pos + 4 <= data_end) {
-            const uint32_t x = pre_pos == pos ? pre : *reinterpret_cast<const u32u*>(raw + pos);
-            if (((~x - 0x01010101u) & x & 0x80808080u) == 0) {
-              acc |= (uint64_t)__builtin_bswap32(x) << (32 - nbits);
-              nbits += 32;
-              pos += 4;
-              pre_pos = pos;
-              pre = *reinterpret_cast<const u32u*>(raw + pos);  // the buffer is padded
-              fast = true;
-            }
-          }
-          while (!fast && nbits <= 56) {
-            uint32_t b = 0;
-            if (pos < data_end) {
-              b = raw[pos++];
-              if (b == 0xFFu && pos < data_end && raw[pos] == 0) ++pos;
-            } else {
-              ++over;
-            }
-            acc |= (uint64_t)b << (56 - nbits);
-            nbits += 8;
-          }
-        }
-        int len;
-        if (k == 0) {
-          const int sz = decode_symbol(hd.look8, hd.maxcode, hd.valoff, hd.vals, acc, len) & 15;
-          int v = 0;
-          if (sz) {
-            v = (int)((acc << len) >> (64 - sz));
-            if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
-          }
-          pred[comp] += v;
-          dc[slot] = pred[comp];
-          acc <<= len + sz;
-          nbits -= len + sz;
-          k = 1;
-        } else {
-          const int rs = decode_symbol(ha.look8, ha.maxcode, ha.valoff, ha.vals, acc, len);
-          const int r = rs >> 4, sz = rs & 15;
-          if (sz) {
-            k += r;
-            if (k < 64) {
-              int v = (int)((acc << len) >> (64 - sz));
-              if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
-              coef[((size_t)(k >> 3) * ntot + slot) * 8 + (k & 7)] = (int16_t)v;
-            }
-            ++k;
-            acc <<= len + sz;
-            nbits -= len + sz;
-          } else {
-            k = r == 15 ? k + 16 : 64;
-            acc <<= len;
-            nbits -= len;
-          }
-        }
-      }
-    }
-  }
-  // bytes invented past the end of the interval that were actually consumed: the interval was cut short
-  if (over * 8 > nbits) *short_flag = 1;
+// DC prediction in a scan with restart intervals: `in` holds the inclusive sums of a component's differences over
+// the whole scan, and every interval starts from zero: out = in - (the sum just before the interval's first block).
+__global__ __launch_bounds__(256) void dc_restart_fix_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                             int ntot, int base1, int base2, int seg0, int seg12) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= ntot) return;
+  const int base = b >= base2 && base2 > 0 ? base2 : (b >= base1 && base1 > 0 ? base1 : 0);
+  const int seg = base == 0 ? seg0 : seg12;
+  const int local = b - base, start = local - local % seg;
+  out[b] = in[b] - (start > 0 ? in[base + start - 1] : 0);
 }
 
 // entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0)
@@ -614,7 +569,7 @@ struct JpegInfo {
   const char* why = "";
   size_t scan_begin = 0, scan_end = 0;
   int restart = 0;            // MCUs per restart interval, 0: none
-  std::vector<uint64_t> rst;  // offsets (from scan_begin) of the first byte behind each RSTn marker
+  std::vector<uint64_t> rst;  // where intervals 1, 2, ... begin: bit positions in the scan without stuffing and markers
   DecTables tabs;
 };
 
@@ -739,18 +694,20 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
     OGD_REQUIRE(have_q[tq[c]] && hd[td[c]].n >= 0 && ha[ta[c]].n >= 0, "JPEG scan refers to a table that was not defined");
   // the entropy-coded segment ends at the first marker that is not stuffing
   size_t e = p;
+  uint64_t nstuff = 0;  // stuffed zero bytes so far
   while (true) {
     const uint8_t* ff = (const uint8_t*)std::memchr(f + e, 0xFF, n - e);
     OGD_REQUIRE(ff && (size_t)(ff - f) + 1 < n, "JPEG scan is not terminated by a marker");
     e = (size_t)(ff - f);
     if (f[e + 1] == 0x00) {
       e += 2;
+      ++nstuff;
       continue;
     }
     if (restart > 0 && f[e + 1] >= 0xD0 && f[e + 1] <= 0xD7) {  // RSTn: the next interval begins behind it
       if ((int)(f[e + 1] - 0xD0) != (int)(info.rst.size() & 7)) JP_UNSUP("restart markers out of order");
       e += 2;
-      info.rst.push_back((uint64_t)(e - p));
+      info.rst.push_back(8 * ((uint64_t)(e - p) - nstuff - 2 * ((uint64_t)info.rst.size() + 1)));
       continue;
     }
     break;
@@ -795,10 +752,6 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   if (restart > 0) {
     const int64_t nint = (nmcu + restart - 1) / restart;
     if ((int64_t)info.rst.size() + 1 != nint) JP_UNSUP("number of restart markers does not match the image");
-    // an interval is one lane's work (decode_intervals_kernel, ~25 us per block against libjpeg's ~0.1 us on a
-    // host core): only worth it with some hundred intervals, or when the whole scan is small
-    const int64_t per_lane = (int64_t)restart * T.bpm, all = nmcu * T.bpm;
-    if (per_lane > std::max<int64_t>(1024, all / 256)) JP_UNSUP("restart intervals too long to be worth a lane each");
   } else if (!info.rst.empty()) {
     JP_UNSUP("restart markers without a restart interval");
   }
@@ -860,43 +813,6 @@ static int blocks_to_image(const JpegInfo& info, const DevBuf& dcoef, const DevB
   return OGD_OK;
 }
 
-// Scans with restart intervals: upload, one lane per interval, then as above.
-static int decode_intervals_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride,
-                                      hipStream_t st) {
-  const int mcux = (info.W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (info.H + 8 * info.v0 - 1) / (8 * info.v0);
-  const int64_t nmcu = (int64_t)mcux * mcuy;
-  const int64_t nblk = info.tabs.ntot;
-  const uint64_t nscan = info.scan_end - info.scan_begin;
-  OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
-  const int nint = (int)info.rst.size() + 1;
-  std::vector<uint64_t> starts((size_t)nint + 1);
-  starts[0] = 0;
-  for (int j = 1; j < nint; ++j) starts[j] = info.rst[j - 1];
-  starts[nint] = nscan;
-  DevBuf draw, dstarts, dtabs, dflag, dcoef, ddc;
-  OGD_TRY(draw.alloc((size_t)nscan + 16));
-  OGD_TRY(dstarts.alloc(starts.size() * sizeof(uint64_t)));
-  OGD_TRY(dtabs.alloc(sizeof(DecTables)));
-  OGD_TRY(dflag.alloc(16));
-  OGD_TRY(dcoef.alloc((size_t)nblk * 64 * sizeof(int16_t)));
-  OGD_TRY(ddc.alloc((size_t)nblk * sizeof(int32_t)));
-  OGD_HIP(hipMemcpyAsync(draw.p, file + info.scan_begin, (size_t)nscan, hipMemcpyHostToDevice, st));
-  OGD_HIP(hipMemcpyAsync(dstarts.p, starts.data(), starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-  OGD_HIP(hipMemcpyAsync(dtabs.p, &info.tabs, sizeof(DecTables), hipMemcpyHostToDevice, st));
-  OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
-  OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
-  const DecTables* tabs = dtabs.as<DecTables>();
-  hipLaunchKernelGGL(decode_intervals_kernel, dim3((unsigned)((nint + 63) / 64)), dim3(64), 0, st, draw.as<uint8_t>(),
-                     dstarts.as<uint64_t>(), nint, tabs, info.restart, nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(),
-                     dflag.as<int>());
-  OGD_TRY(check_launch("decode_intervals_kernel"));
-  int cut_short = 0;
-  OGD_HIP(hipMemcpyAsync(&cut_short, dflag.p, sizeof cut_short, hipMemcpyDeviceToHost, st));
-  OGD_HIP(hipStreamSynchronize(st));  // also: `starts` and the tables have been read
-  if (cut_short) return fail(OGD_ERR_RUNTIME, "a restart interval of the JPEG scan ends before its blocks do");
-  return blocks_to_image(info, dcoef, ddc, tabs, d_img, stride, st);
-}
-
 static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* d_img, ptrdiff_t stride, hipStream_t st) {
   const int H = info.H, W = info.W;
   const int mcux = (W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (H + 8 * info.v0 - 1) / (8 * info.v0);
@@ -904,8 +820,6 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   const int64_t nblk = info.tabs.ntot;  // coefficient slots = blocks of all components
   const uint64_t nscan = info.scan_end - info.scan_begin;
   OGD_REQUIRE(nscan >= 1 && nscan < ((uint64_t)1 << 40), "empty JPEG scan");
-
-  if (info.restart > 0) return decode_intervals_to_device(file, info, d_img, stride, st);
 
   // D1
   const int64_t nun64 = (int64_t)((nscan + UN_CHUNK - 1) / UN_CHUNK);
@@ -946,15 +860,28 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_TRY(check_launch("init_states_kernel"));
   const DecTables* tabs = dtabs.as<DecTables>();
   const bool multi = info.tabs.bpm > 1;
-  const auto state_pass = multi ? &decode_chunks_kernel<false, true> : &decode_chunks_kernel<false, false>;
-  const auto write_pass = multi ? &decode_chunks_kernel<true, true> : &decode_chunks_kernel<true, false>;
+  const bool rst = info.restart > 0 && !info.rst.empty();  // a DRI file of one interval is an ordinary scan
+  const auto state_pass = multi ? (rst ? &decode_chunks_kernel<false, true, true> : &decode_chunks_kernel<false, true, false>)
+                                : (rst ? &decode_chunks_kernel<false, false, true> : &decode_chunks_kernel<false, false, false>);
+  const auto write_pass = multi ? (rst ? &decode_chunks_kernel<true, true, true> : &decode_chunks_kernel<true, true, false>)
+                                : (rst ? &decode_chunks_kernel<true, false, true> : &decode_chunks_kernel<true, false, false>);
+  DevBuf drst, dcheck;
+  const int nrst = rst ? (int)info.rst.size() : 0;
+  if (rst) {
+    OGD_TRY(drst.alloc(info.rst.size() * sizeof(uint64_t)));
+    OGD_TRY(dcheck.alloc(16));
+    OGD_HIP(hipMemcpyAsync(drst.p, info.rst.data(), info.rst.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    OGD_HIP(hipMemsetAsync(dcheck.p, 0, 8, st));
+  }
+  const uint64_t* rst_bits = drst.as<uint64_t>();
   int rounds = 0;
   while (true) {
     OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
     hipLaunchKernelGGL(state_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
                        (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
-                       rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)));
+                       rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)), rst_bits, nrst, info.restart,
+                       (int*)nullptr);
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;
     OGD_HIP(hipMemcpyAsync(&changed, dflag.p, sizeof changed, hipMemcpyDeviceToHost, st));
@@ -987,7 +914,8 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_HIP(hipMemsetAsync(dcoef.p, 0, (size_t)nblk * 64 * sizeof(int16_t), st));
   hipLaunchKernelGGL(write_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
-                     dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0);
+                     dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0, rst_bits, nrst, info.restart,
+                     dcheck.as<int>());
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
   // D5: DC prediction runs per component, in stream order: one inclusive scan per component's slots
   {
@@ -1003,7 +931,22 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
       OGD_HIP(hipcub::DeviceScan::InclusiveSum(dtmp3.p, sbc, ddc.as<int32_t>() + starts[c], ddc.as<int32_t>() + starts[c], cnt, st));
     }
   }
-  OGD_TRY(blocks_to_image(info, dcoef, ddc, tabs, d_img, stride, st));
+  DevBuf ddc2;
+  if (rst) {
+    int check[2] = {0, 0};
+    OGD_HIP(hipMemcpyAsync(check, dcheck.p, sizeof check, hipMemcpyDeviceToHost, st));
+    OGD_TRY(ddc2.alloc((size_t)nblk * sizeof(int32_t)));
+    hipLaunchKernelGGL(dc_restart_fix_kernel, dim3((unsigned)((nblk + 255) / 256)), blk, 0, st, ddc.as<int32_t>(),
+                       ddc2.as<int32_t>(), (int)nblk, info.tabs.base[1], info.tabs.base[2], info.restart * info.tabs.n0,
+                       info.restart);
+    OGD_TRY(check_launch("dc_restart_fix_kernel"));
+    OGD_HIP(hipStreamSynchronize(st));
+    if (std::getenv("OGD_JPEG_DEBUG")) fprintf(stderr, "ogd_jpeg_decode: restarts taken %d of %d, misplaced %d\n", check[0], nrst, check[1]);
+    if (check[0] != nrst || check[1])
+      return fail(OGD_ERR_RUNTIME, "JPEG scan: %d of %d restart intervals begin where their markers stand%s", check[0], nrst,
+                  check[1] ? ", not all after the right number of blocks" : "");
+  }
+  OGD_TRY(blocks_to_image(info, dcoef, rst ? ddc2 : ddc, tabs, d_img, stride, st));
   OGD_HIP(hipStreamSynchronize(st));  // the scratch buffers go back to the block cache on return
   return OGD_OK;
 }

@@ -86,8 +86,9 @@ void* pool_take(size_t bytes) {
   PoolBlock* best = nullptr;
   for (auto& b : g_pool.blocks)
     if (!b.busy && b.device == dev && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
-  // a block more than 4x too large stays free for a larger request
-  if (best && best->bytes <= 4 * bytes + (1u << 20)) {
+  // a block more than 4x too large stays free for a larger request (blocks come in 2 MiB granules: the allowance
+  // lets small requests share them instead of each taking a new granule on every call)
+  if (best && best->bytes <= 4 * bytes + (4u << 20)) {
     best->busy = true;
     return best->p;
   }

@@ -158,7 +158,7 @@ def _check_file(gpu, data):
 
 @pytest.mark.parametrize("shape", [(8, 8), (17, 33), (250, 301), (640, 999)])
 @pytest.mark.parametrize("restart", [dict(restart_marker_rows=1), dict(restart_marker_blocks=1),
-	dict(restart_marker_blocks=3), dict(restart_marker_blocks=17), dict(restart_marker_rows=2)])
+	dict(restart_marker_blocks=3), dict(restart_marker_blocks=17), dict(restart_marker_rows=4)])
 def test_scans_with_restart_intervals(gpu, shape, restart):
 	"""DRI: every interval is byte-aligned and starts its DC predictions anew; more than eight markers (RST0-7 cycle)."""
 	rng = np.random.default_rng(shape[0] + shape[1])
@@ -176,12 +176,21 @@ def test_restart_intervals_text_pages_and_fitted_tables(gpu):
 	_check_file(gpu, _restart_file(np.full((300, 200), 255, np.uint8), restart_marker_blocks=5))  # all-ones bytes: stuffing
 
 
+def test_restart_intervals_long_colour_streams(gpu):
+	"""More than 65536 chunks of 1024 bits with three components (a case that once decoded wrongly)."""
+	rng = np.random.default_rng(24)
+	noise = rng.integers(0, 256, size=(1600, 2000, 3), dtype=np.uint8)
+	_check_file(gpu, _restart_file(noise, restart_marker_rows=1, subsampling=0, quality=98))
+	_check_file(gpu, _restart_file(noise, restart_marker_blocks=7, subsampling=2, quality=100))
+	_check_file(gpu, _restart_file(synth.colour_page(rng, (6000, 8000)), restart_marker_rows=1, quality=85))
+
+
 def test_restart_intervals_whole_broadsheet_scan(gpu):
 	rng = np.random.default_rng(22)
 	_check_file(gpu, _restart_file(synth.text_page(rng, (6000, 8000)), restart_marker_rows=1))
 
 
-def test_restart_intervals_damaged_or_too_long(gpu):
+def test_restart_intervals_damaged_or_long(gpu):
 	rng = np.random.default_rng(23)
 	page = synth.text_page(rng, (512, 384))
 	data = bytearray(_restart_file(page, restart_marker_rows=1))
@@ -203,9 +212,9 @@ def test_restart_intervals_damaged_or_too_long(gpu):
 				bad[q] = int(rng.integers(0, 255))
 		out = gpu.jpeg_decode_gray(bytes(bad))
 		assert out is None or out.shape == (384, 512)
-	# one interval for a whole large scan: a single lane would decode it -> left to PIL
-	big = _restart_file(synth.text_page(rng, (2400, 3400)), restart_marker_rows=500)
-	assert gpu.jpeg_info(big)[3] is False
+	# a DRI segment but one interval for the whole scan, and two long ones
+	_check_file(gpu, _restart_file(synth.text_page(rng, (2400, 3400)), restart_marker_rows=500))
+	_check_file(gpu, _restart_file(synth.text_page(rng, (2400, 3400)), restart_marker_rows=213))
 	_check_file(gpu, bytes(data))
 
 
