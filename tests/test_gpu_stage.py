@@ -254,3 +254,32 @@ def test_dewarped_image_stage_on_a_jpeg_scan(gpu, tmp_path):
 	ref = io.BytesIO()
 	want.save(ref, format="JPEG")
 	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()
+
+
+def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tmp_path):
+	"""A colour scan (JFIF YCbCr 4:2:0, a restart marker per MCU row): the reference opens it with
+	`.convert("L")` (origami/core/page.py:82-84); here it is decoded to "L" on the device, and the stage's output is
+	the file PIL writes for the oracle's dewarp of PIL's own "L" pixels."""
+	import PIL.Image
+	from oracle import dewarp as odw2
+	from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
+	from origami_amd.page import Page
+	rng = np.random.default_rng(33)
+	size = (648, 470)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=100, n_v=120, n_regions=8, n_separators=2, label_size=(324, 235),
+		suffix=".jpg")
+	PIL.Image.fromarray(synth.colour_page(rng, size)).save(page_path, format="JPEG", quality=88, restart_marker_rows=1)
+	assert PIL.Image.open(page_path).mode == "RGB"
+	assert gpu.jpeg_info(page_path.read_bytes())[2:] == (3, True)
+	pixels = np.array(PIL.Image.open(page_path).convert("L"))
+	assert np.array_equal(np.array(Page(page_path).warped), pixels)  # device decode == PIL decode + convert
+	out = page_path.with_suffix(".out")
+	assert CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"]).exit_code == 0
+	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	nodes = Grid.open(out / "dewarp.zip").points("sample")
+	want = PIL.Image.fromarray(odw2.dewarped(pixels, odw2.Grid(nodes, 25)))
+	ref = io.BytesIO()
+	want.save(ref, format="JPEG")
+	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()
