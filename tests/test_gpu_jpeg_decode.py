@@ -283,3 +283,23 @@ def test_damaged_scans_never_fault_or_hang(gpu):
 		assert out is None or out.shape == (384, 512)
 	# a healthy file still decodes afterwards (nothing was left in a bad state)
 	assert np.array_equal(gpu.jpeg_decode_gray(bytes(data)), _pil_decode(bytes(data)))
+
+
+@pytest.mark.parametrize("params", [dict(subsampling=2), dict(subsampling=0), dict(subsampling=2, restart_marker_rows=1),
+	dict(subsampling=1, restart_marker_blocks=5)])
+def test_damaged_colour_scans_never_fault_or_hang(gpu, params):
+	"""As test_damaged_scans_never_fault_or_hang, for three-component scans with and without restart intervals."""
+	rng = np.random.default_rng(25)
+	data = bytearray(_colour_file(synth.colour_page(rng, (512, 384)), quality=80, **params))
+	start = data.index(b"\xff\xda") + 14
+	for trial in range(10):
+		bad = bytearray(data)
+		for pos in rng.integers(start, len(bad) - 2, size=1 + trial * 8):
+			if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:  # markers and stuffing stay intact
+				bad[pos] = int(rng.integers(0, 255))
+		try:
+			out = gpu.jpeg_decode_gray(bytes(bad))
+		except gpu.OgdError:
+			continue
+		assert out is None or out.shape == (384, 512)
+	_check_file(gpu, bytes(data))
