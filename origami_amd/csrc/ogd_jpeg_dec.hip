@@ -204,6 +204,22 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
     ri = lo;
     if (ri < nrst) next_rst = rst_bits[ri];
   }
+  // the current block's tables and coefficient slot (component-major, stream order inside a component): looked up
+  // when the block changes, not per symbol
+  const DecHuff* hd = &t.dc[0];
+  const DecHuff* ha = &t.ac[0];
+  size_t slot = (size_t)mcu;
+  auto select_block = [&]() {
+    if (MULTI) {
+      const int comp = t.blk_comp[m];
+      hd = &t.dc[t.dc_sel[comp]];
+      ha = &t.ac[t.ac_sel[comp]];
+      if (WRITE) slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
+    } else if (WRITE) {
+      slot = (size_t)mcu;
+    }
+  };
+  select_block();
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
   uint64_t p0 = p, w0 = window(s, p);
 walk:
@@ -214,12 +230,8 @@ walk:
     }
     const uint64_t w = w0 << (p - p0);
     int len;
-    const int comp = MULTI ? t.blk_comp[m] : 0;
-    // coefficient slot of the current block: component-major, stream order inside a component
-    const size_t slot = MULTI ? (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu) : (size_t)mcu;
     if (k == 0) {
-      const DecHuff& hd = t.dc[MULTI ? t.dc_sel[comp] : 0];
-      const int sz = decode_symbol(hd.look8, hd.maxcode, hd.valoff, hd.vals, w, len) & 15;
+      const int sz = decode_symbol(hd->look8, hd->maxcode, hd->valoff, hd->vals, w, len) & 15;
       if (WRITE && mcu < nmcu) {
         int v = 0;
         if (sz) {
@@ -231,8 +243,7 @@ walk:
       p += (uint64_t)(len + sz);
       k = 1;
     } else {
-      const DecHuff& ha = t.ac[MULTI ? t.ac_sel[comp] : 0];
-      const int rs = decode_symbol(ha.look8, ha.maxcode, ha.valoff, ha.vals, w, len);
+      const int rs = decode_symbol(ha->look8, ha->maxcode, ha->valoff, ha->vals, w, len);
       const int r = rs >> 4, sz = rs & 15;
       if (sz) {
         k += r;
@@ -260,6 +271,7 @@ walk:
           m = 0;
           ++mcu;
         }
+        select_block();
         if (RST && m == 0) {
           while (next_rst < p) {  // passed without a restart: this walk is on a wrong parse
             ++ri;
