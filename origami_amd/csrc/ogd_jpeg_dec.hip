@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
                                                             const uint64_t* __restrict__ first_block, int64_t nmcu,
                                                             int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff,
                                                             int forward, const uint64_t* __restrict__ rst_bits, int nrst,
-                                                            int restart, int* __restrict__ rst_check) {
+                                                            int restart, int* __restrict__ rst_check,
+                                                            const uint8_t* __restrict__ dirty, uint8_t* __restrict__ touched) {
   __shared__ DecTables t;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
@@ -182,6 +183,9 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunk) return;
+  // State pass: a chunk whose entry state is the one it was last walked from, and whose published exit nobody else
+  // has written since, would reproduce that exit: skipped (shift_states_kernel keeps the books).
+  if (!WRITE && !dirty[i]) return;
   uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
   ChunkState st = entry[i];
   uint64_t p = st.p;
@@ -307,6 +311,7 @@ walk:
       ns.k = k;
       ns.m = m;
       exit_state[c] = ns;
+      if (c != i) touched[c] = 1;  // chunk c's own walk has to confirm this next round
     }
     if (c == i || !same) nblocks[c] = blocks;
     // Where the stream is periodic (a blank margin: every block the same six bits) a wrong parse can be
@@ -338,25 +343,28 @@ __global__ __launch_bounds__(256) void dc_restart_fix_kernel(const int32_t* __re
   out[b] = in[b] - (start > 0 ? in[base + start - 1] : 0);
 }
 
-// entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0)
+// entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0).  dirty[i]: chunk i has to be walked again — its
+// entry changed, or a forward walk of another thread wrote its exit state in the round before.
 __global__ __launch_bounds__(256) void shift_states_kernel(const ChunkState* __restrict__ exit_state, int nchunk,
-                                                           ChunkState* __restrict__ entry) {
+                                                           ChunkState* __restrict__ entry, uint8_t* __restrict__ dirty,
+                                                           uint8_t* __restrict__ touched) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunk) return;
-  if (i == 0) {
-    ChunkState z;
-    z.p = 0;
-    z.k = 0;
-    z.m = 0;
-    entry[0] = z;
-  } else {
-    entry[i] = exit_state[i - 1];
-  }
+  ChunkState z;
+  z.p = 0;
+  z.k = 0;
+  z.m = 0;
+  if (i > 0) z = exit_state[i - 1];
+  const ChunkState old = entry[i];
+  dirty[i] = (uint8_t)(touched[i] || old.p != z.p || old.k != z.k || old.m != z.m);
+  touched[i] = 0;
+  entry[i] = z;
 }
 
 __global__ __launch_bounds__(256) void init_states_kernel(int nchunk, ChunkState* __restrict__ entry,
                                                           ChunkState* __restrict__ exit_state,
-                                                          uint64_t* __restrict__ nblocks) {
+                                                          uint64_t* __restrict__ nblocks, uint8_t* __restrict__ dirty,
+                                                          uint8_t* __restrict__ touched) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i > nchunk) return;
   if (i == nchunk) {
@@ -370,6 +378,8 @@ __global__ __launch_bounds__(256) void init_states_kernel(int nchunk, ChunkState
   entry[i] = z;
   z.p = ~0ull;
   exit_state[i] = z;
+  dirty[i] = 1;
+  touched[i] = 0;
 }
 
 // ---- D6 ------------------------------------------------------------------------------------------------
@@ -861,14 +871,17 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   const int64_t nchunk64 = (int64_t)((total_bits + CHUNK_BITS - 1) / CHUNK_BITS);
   OGD_REQUIRE(nchunk64 >= 1 && nchunk64 < INT_MAX - 256, "JPEG scan too long");
   const int nchunk = (int)nchunk64;
-  DevBuf dentry, dexit, dnb, dflag, dtmp2;
+  DevBuf dentry, dexit, dnb, dflag, dtmp2, ddirty;
   OGD_TRY(dentry.alloc((size_t)nchunk * sizeof(ChunkState)));
   OGD_TRY(dexit.alloc((size_t)nchunk * sizeof(ChunkState)));
   OGD_TRY(dnb.alloc(((size_t)nchunk + 1) * sizeof(uint64_t)));
   OGD_TRY(dflag.alloc(16));
+  OGD_TRY(ddirty.alloc(2 * (size_t)nchunk));
+  uint8_t* const dirty = ddirty.as<uint8_t>();
+  uint8_t* const touched = dirty + nchunk;
   const dim3 cgrid((unsigned)((nchunk + 255) / 256)), cgrid1((unsigned)((nchunk + 1 + 255) / 256)), blk(256);
   hipLaunchKernelGGL(init_states_kernel, cgrid1, blk, 0, st, nchunk, dentry.as<ChunkState>(), dexit.as<ChunkState>(),
-                     dnb.as<uint64_t>());
+                     dnb.as<uint64_t>(), dirty, touched);
   OGD_TRY(check_launch("init_states_kernel"));
   const DecTables* tabs = dtabs.as<DecTables>();
   const bool multi = info.tabs.bpm > 1;
@@ -893,7 +906,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
                        (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
                        rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)), rst_bits, nrst, info.restart,
-                       (int*)nullptr);
+                       (int*)nullptr, dirty, touched);
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;
     OGD_HIP(hipMemcpyAsync(&changed, dflag.p, sizeof changed, hipMemcpyDeviceToHost, st));
@@ -904,7 +917,8 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     // A scan that has not settled after 1024 rounds is damaged or adversarial: leave it to the caller's decoder.
     if (rounds > 1024 || rounds > nchunk + 1)
       return fail(OGD_ERR_RUNTIME, "JPEG chunk states did not settle in %d rounds", rounds);
-    hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>());
+    hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>(),
+                       dirty, touched);
     OGD_TRY(check_launch("shift_states_kernel"));
   }
   // the last round ran from entry = shifted exits of the round before and reproduced them: entry is exact
@@ -927,7 +941,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   hipLaunchKernelGGL(write_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
                      dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0, rst_bits, nrst, info.restart,
-                     dcheck.as<int>());
+                     dcheck.as<int>(), (const uint8_t*)nullptr, (uint8_t*)nullptr);
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
   // D5: DC prediction runs per component, in stream order: one inclusive scan per component's slots
   {
