@@ -118,7 +118,7 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
  * ref: origami/core/page.py:82-84 (`PIL.Image.open(path).convert("L")`).  A baseline JPEG decoder on the device
  * for 8-bit Huffman files without restart markers, one component (grayscale) or three (JFIF YCbCr in one
  * interleaved scan, 4:4:4 / 4:2:2 / 4:2:0): the pixels `convert("L")` gives after PIL / libjpeg-turbo decoded the
- * file, bit for bit (Huffman decoding in parallel by fixed-point iteration over 1024-bit chunks, islow IDCT,
+ * file, bit for bit (Huffman decoding in parallel by fixed-point iteration over 512-bit chunks, islow IDCT,
  * libjpeg's fancy chroma upsampling and YCbCr -> RGB tables, PIL's RGB -> L).
  * ogd_jpeg_info: size and component count of any JPEG file; *supported = 1 if this decoder covers it (else
  * ogd_last_error() names the reason and the caller keeps its own decoder — progressive, DRI, CMYK / Adobe ...).

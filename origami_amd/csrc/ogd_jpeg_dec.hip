@@ -14,7 +14,7 @@
 // The entropy-coded segment is one long bit string; where a block starts is known only by decoding everything
 // before it.  It is decoded in parallel all the same, by iterating to a fixed point:
 //   D1 unstuff        0xFF 0x00 -> 0xFF (count per 4 KB chunk, scan, compact)
-//   D2 decode_chunks  thread per 1024-bit chunk: starts from the state (bit position, coefficient index) at
+//   D2 decode_chunks  thread per 512-bit chunk: starts from the state (bit position, coefficient index) at
 //                     which its predecessor LEFT its chunk in the previous round (round 0: the chunk border,
 //                     index 0), decodes to the end of its own chunk and publishes its exit state.  Chunk 0 always
 //                     starts right, so after round r chunks 0..r are exact; Huffman streams re-synchronise
@@ -32,7 +32,7 @@
 namespace ogd {
 namespace {
 
-constexpr int CHUNK_BITS = 1024;
+constexpr int CHUNK_BITS = 512;
 constexpr int UN_CHUNK = 4096;
 
 struct DecHuff {        // one Huffman table, decoder form
@@ -905,7 +905,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     hipLaunchKernelGGL(state_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
                        (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
-                       rounds < 3 ? 0 : std::min(2048, 4 << std::min(rounds - 3, 12)), rst_bits, nrst, info.restart,
+                       rounds < 3 ? 0 : std::min(2048 * (1024 / CHUNK_BITS), (4 * (1024 / CHUNK_BITS)) << std::min(rounds - 3, 12)), rst_bits, nrst, info.restart,
                        (int*)nullptr, dirty, touched);
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;

@@ -177,7 +177,7 @@ def test_restart_intervals_text_pages_and_fitted_tables(gpu):
 
 
 def test_restart_intervals_long_colour_streams(gpu):
-	"""More than 65536 chunks of 1024 bits with three components (a case that once decoded wrongly)."""
+	"""More than 65536 chunks with three components (a case that once decoded wrongly)."""
 	rng = np.random.default_rng(24)
 	noise = rng.integers(0, 256, size=(1600, 2000, 3), dtype=np.uint8)
 	_check_file(gpu, _restart_file(noise, restart_marker_rows=1, subsampling=0, quality=98))
