@@ -50,6 +50,7 @@ struct DecTables {
   int32_t n0;                    // blocks of component 0 per MCU (h0 * v0)
   int32_t base[3];               // first coefficient slot of each component
   int32_t ntot;                  // slots in all
+  uint32_t dc_mask, ac_mask;     // bit m: block m of an MCU uses dc[1] / ac[1]
 };
 
 static bool build_dec_huff(const uint8_t* bits, const uint8_t* vals, int nvals, DecHuff& h) {
@@ -139,12 +140,15 @@ __device__ __forceinline__ int decode_symbol(const uint16_t* __restrict__ look8,
     len = (int)(e >> 8);
     return (int)(e & 255u);
   }
-  for (int l = 9; l <= 16; ++l) {
-    const int c = (int)(c16 >> (16 - l));
-    if (c <= maxcode[l]) {
-      len = l;
-      return vals[(c + valoff[l]) & 255];
-    }
+  // longer codes: all eight length tests at once (the loads do not depend on each other; a wave nearly always
+  // holds a lane with a long code, so a loop with an early exit costs every symbol its full chain of LDS reads)
+  uint32_t fits = 0;
+#pragma unroll
+  for (int l = 9; l <= 16; ++l) fits |= (uint32_t)((int)(c16 >> (16 - l)) <= maxcode[l]) << (l - 9);
+  if (fits) {
+    const int l = 8 + __ffs((int)fits);
+    len = l;
+    return vals[((int)(c16 >> (16 - l)) + valoff[l]) & 255];
   }
   len = 16;
   return 0;
@@ -213,12 +217,16 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   const DecHuff* hd = &t.dc[0];
   const DecHuff* ha = &t.ac[0];
   size_t slot = (size_t)mcu;
+  const int bpm = t.bpm, n0 = t.n0;
+  const uint32_t dc_mask = t.dc_mask, ac_mask = t.ac_mask;
   auto select_block = [&]() {
-    if (MULTI) {
-      const int comp = t.blk_comp[m];
-      hd = &t.dc[t.dc_sel[comp]];
-      ha = &t.ac[t.ac_sel[comp]];
-      if (WRITE) slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * t.n0 + m : mcu);
+    if (MULTI) {  // no LDS look-up on the state pass: a lone forward walk pays every one of them in full
+      hd = &t.dc[(dc_mask >> m) & 1u];
+      ha = &t.ac[(ac_mask >> m) & 1u];
+      if (WRITE) {
+        const int comp = m < n0 ? 0 : m - n0 + 1;
+        slot = (size_t)t.base[comp] + (size_t)(comp == 0 ? mcu * n0 + m : mcu);
+      }
     } else if (WRITE) {
       slot = (size_t)mcu;
     }
@@ -271,7 +279,7 @@ walk:
         ++blocks;
         if (!MULTI) {
           ++mcu;
-        } else if (++m >= t.bpm) {
+        } else if (++m >= bpm) {
           m = 0;
           ++mcu;
         }
@@ -763,7 +771,11 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   info.v0 = info.ncomp == 3 ? vs[0] : 1;
   T.n0 = info.h0 * info.v0;
   T.bpm = info.ncomp == 3 ? T.n0 + 2 : 1;
-  for (int m2 = 0; m2 < T.bpm; ++m2) T.blk_comp[m2] = (uint8_t)(m2 < T.n0 ? 0 : m2 - T.n0 + 1);
+  for (int m2 = 0; m2 < T.bpm; ++m2) {
+    T.blk_comp[m2] = (uint8_t)(m2 < T.n0 ? 0 : m2 - T.n0 + 1);
+    T.dc_mask |= (uint32_t)T.dc_sel[T.blk_comp[m2]] << m2;
+    T.ac_mask |= (uint32_t)T.ac_sel[T.blk_comp[m2]] << m2;
+  }
   const int64_t mcux = (info.W + 8 * info.h0 - 1) / (8 * info.h0), mcuy = (info.H + 8 * info.v0 - 1) / (8 * info.v0);
   const int64_t nmcu = mcux * mcuy;
   OGD_REQUIRE(nmcu * T.bpm < INT_MAX - 256, "too many blocks");
