@@ -3,7 +3,7 @@
 // This is a baseline JPEG decoder for 8-bit Huffman files: one component (grayscale), or
 // three (YCbCr, one interleaved scan, luma sampled 1x1, 2x1 or 2x2) converted to "L" the way PIL does it after
 // libjpeg's fancy upsampling and YCbCr -> RGB.  Its pixels are the ones `Image.open(f).convert("L")` gives, bit
-// for bit (tests/ compare with PIL itself).  Scans with restart intervals (DRI) are decoded interval by interval.
+// for bit (tests/ compare with PIL itself).  Scans with restart intervals (DRI) go through the same passes.
 // Anything else (progressive, arithmetic coding, 12 bit, CMYK, Adobe files) returns OGD_ERR_UNSUPPORTED and the
 // caller keeps PIL.
 //
@@ -13,16 +13,20 @@
 //
 // The entropy-coded segment is one long bit string; where a block starts is known only by decoding everything
 // before it.  It is decoded in parallel all the same, by iterating to a fixed point:
-//   D1 unstuff        0xFF 0x00 -> 0xFF (count per 4 KB chunk, scan, compact)
+//   D1 unstuff        0xFF 0x00 -> 0xFF, RSTn markers dropped (count per 4 KB chunk, scan, compact)
 //   D2 decode_chunks  thread per 512-bit chunk: starts from the state (bit position, coefficient index) at
 //                     which its predecessor LEFT its chunk in the previous round (round 0: the chunk border,
 //                     index 0), decodes to the end of its own chunk and publishes its exit state.  Chunk 0 always
 //                     starts right, so after round r chunks 0..r are exact; Huffman streams re-synchronise
 //                     within a few dozen symbols, so in practice everything is exact after a handful of
-//                     rounds.  The host stops when a round changes no state.
+//                     rounds.  The host stops when a round changes no state.  From the second round on only chunks
+//                     whose entry changed (or whose exit another thread's forward walk wrote) are walked again.
+//                     With restart intervals a walk that ends an MCU just in front of an interval start (host
+//                     list) continues there with a fresh block.
 //   D3 scan of the blocks completed per chunk -> first block of every chunk
 //   D4 decode_chunks<WRITE>  the same walk, now storing DC differences and AC coefficients
-//   D5 inclusive scan of the DC differences (hipCUB), D6 idct_kernel: thread per 8x8 block
+//   D5 inclusive scan of the DC differences per component (hipCUB; restart intervals: minus the sum in front
+//      of the interval), D6 idct_kernel: thread per 8x8 block, D7 ycc_to_l_kernel (three components)
 #include "ogd_common.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
