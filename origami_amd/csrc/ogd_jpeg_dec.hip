@@ -30,6 +30,7 @@
 #include "ogd_common.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -916,6 +917,12 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   }
   const uint64_t* rst_bits = drst.as<uint64_t>();
   int rounds = 0;
+  // A stream that is periodic throughout (a flat page, a synthetic pattern) is walked by single lanes, chunk after
+  // chunk: slower than libjpeg on a host core.  Time allowance for the rounds: twice what libjpeg would need for the
+  // whole file (~1 ns per sample + 3 ns per scan byte) + 100 ms; past it the file is handed back (a 12 MP 1-pixel
+  // checkerboard would take 2.5 s).
+  const auto t_rounds = std::chrono::steady_clock::now();
+  const double allowance_ms = 100.0 + 2e-6 * (1.0 * (double)H * W * info.ncomp + 3.0 * (double)nscan);
   while (true) {
     OGD_HIP(hipMemsetAsync(dflag.p, 0, 4, st));
     hipLaunchKernelGGL(state_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
@@ -933,6 +940,11 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     // A scan that has not settled after 1024 rounds is damaged or adversarial: leave it to the caller's decoder.
     if (rounds > 1024 || rounds > nchunk + 1)
       return fail(OGD_ERR_RUNTIME, "JPEG chunk states did not settle in %d rounds", rounds);
+    if (rounds >= 6) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rounds).count();
+      if (ms > allowance_ms)
+        return fail(OGD_ERR_RUNTIME, "JPEG chunk states settle too slowly (periodic stream): %d rounds in %.0f ms", rounds, ms);
+    }
     hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>(),
                        dirty, touched);
     OGD_TRY(check_launch("shift_states_kernel"));

@@ -56,6 +56,20 @@ def test_flat_and_extreme_images(gpu):
 		_check(gpu, (((yy // period + xx // period) & 1) * 255).astype(np.uint8), quality=100)
 
 
+def test_large_periodic_stream_is_handed_back_in_bounded_time(gpu):
+	"""A 1-pixel checkerboard at quality 100: every block the same ~700 bits, wrong parses are self-consistent and
+	single lanes would walk the whole 5 MB stream (seconds).  The decoder gives up after its time allowance and the
+	caller keeps PIL."""
+	import time
+	yy, xx = np.mgrid[0:3000, 0:2000]
+	data = ojpeg.save_gray((((yy + xx) & 1) * 255).astype(np.uint8), quality=100)
+	t0 = time.perf_counter()
+	got = gpu.jpeg_decode_gray(data)
+	dt = time.perf_counter() - t0
+	assert dt < 1.5, "%.2f s" % dt
+	assert got is None or np.array_equal(got, _pil_decode(data))
+
+
 def test_files_outside_the_domain_are_refused_not_misdecoded(gpu):
 	rng = np.random.default_rng(4)
 	rgb = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
