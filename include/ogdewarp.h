@@ -123,7 +123,9 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
  * ogd_jpeg_info: size and component count of any JPEG file; *supported = 1 if this decoder covers it (else
  * ogd_last_error() names the reason and the caller keeps its own decoder — progressive, DRI, CMYK / Adobe ...).
  * ogd_jpeg_decode_gray: file bytes -> [H][W] uint8 (host, row stride in bytes); OGD_ERR_UNSUPPORTED for a file
- * outside the decoder's domain, OGD_ERR_RUNTIME for a scan with too few blocks.  _dev: output in device memory.
+ * outside the decoder's domain; OGD_ERR_RUNTIME for a scan this decoder gives up on (too few blocks, restart
+ * markers that do not stand where the blocks say, a stream periodic throughout whose chunk states settle too
+ * slowly): the caller keeps its own decoder then, too.  _dev: output in device memory.
  */
 int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* supported);
 /* scan file in -> dewarped page's file out (decode, ogd_dewarp_u8 with C = 1, scale 1, linear, encode: the
