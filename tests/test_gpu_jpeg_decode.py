@@ -88,6 +88,7 @@ def test_files_outside_the_domain_are_refused_not_misdecoded(gpu):
 	PIL.Image.fromarray(rgb[:, :, 0]).save(buf, format="JPEG", progressive=True)
 	assert gpu.jpeg_info(buf.getvalue())[3] is False
 	assert gpu.jpeg_decode_gray(buf.getvalue()) is None
+	assert gpu.jpeg_info(ojpeg.save_gray(np.full((3000, 2000), 255, np.uint8)))[3] is False  # a large blank page
 	with pytest.raises(gpu.OgdError):
 		gpu.jpeg_info(b"not a jpeg file at all")
 
