@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
     }
   };
   select_block();
+  uint64_t pb = ~0ull;  // where the current block began (if on this walk)
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
   uint64_t p0 = p, w0 = window(s, p);
 walk:
@@ -248,6 +249,7 @@ walk:
     const uint64_t w = w0 << (p - p0);
     int len;
     if (k == 0) {
+      pb = p;
       const int sz = decode_symbol(hd->look8, hd->maxcode, hd->valoff, hd->vals, w, len) & 15;
       if (WRITE && mcu < nmcu) {
         int v = 0;
@@ -289,6 +291,24 @@ walk:
           ++mcu;
         }
         select_block();
+        if (!WRITE && !MULTI && !RST && pb != ~0ull && p - pb <= 28) {
+          // Blank paper: the same few bits block after block.  A block's parse is a function of exactly the bits
+          // it consumed, so while the next L bits repeat them the next block ends L bits on — counted without
+          // decoding, several per load, as long as it ends inside the chunk (where the plain walk would stop too).
+          const uint32_t L = (uint32_t)(p - pb);
+          const uint64_t pat = window(s, pb) >> (64 - L);
+          const uint32_t per_load = 57u / L;
+          for (;;) {
+            const uint64_t wq = window(s, p);
+            uint32_t j = 0;
+            while (j < per_load && p + L <= end && ((wq << (j * L)) >> (64 - L)) == pat) {
+              ++j;
+              p += L;
+            }
+            blocks += j;
+            if (j < per_load) break;
+          }
+        }
         if (RST && m == 0) {
           while (next_rst < p) {  // passed without a restart: this walk is on a wrong parse
             ++ri;
