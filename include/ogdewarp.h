@@ -260,6 +260,18 @@ int ogd_march_grid(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h
                    const ogd_tri* inner_v, const ogd_tri* extra_v, double phi0_v,
                    const double* bounds, int s, int n_rows, int n_cols, int num_slices,
                    float* grid_h, float* grid_hv);
+/* ogd_march_grid for callers that cannot allocate.  No counterpart in the reference: it exists for callers that
+ * may not call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same results (it runs the same kernels), but its device buffers — both node grids, the slice
+ * ray lengths, the status record — are a fixed ~4 MiB array in the library's device image, held by every GPU the
+ * library runs on until the process ends; no hipMalloc / hipFree or other allocating routine is called.
+ * Limits: n_rows * n_cols <= 262144 nodes and at most 1024 column slices, else OGD_ERR_INVALID (use
+ * ogd_march_grid).  All calls on one GPU share that array: calls that overlap on the same GPU race, so
+ * serialise them per GPU (the array keeps the last call's contents; each call resets what it reads). */
+int ogd_march_grid_noalloc(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h,
+                           const ogd_tri* inner_v, const ogd_tri* extra_v, double phi0_v,
+                           const double* bounds, int s, int n_rows, int n_cols, int num_slices,
+                           float* grid_h, float* grid_hv);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,9 @@ SIGNATURES = {
 	"ogd_march_grid": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
 		c_void_p, c_void_p]),
+	"ogd_march_grid_noalloc": (c_int, [
+		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
+		c_void_p, c_void_p]),
 	"ogd_jpeg_encode_gray": (c_int, [c_void_p, c_int, c_int, c_ssize_t, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
 	"ogd_jpeg_encode_gray_dev": (c_int, [
 		c_void_p, c_int, c_int, c_ssize_t, c_int, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
@@ -573,12 +576,14 @@ def march_shape(field_h, field_v, bounds, width, height, cell):
 	return n_rows.value, n_cols.value
 
 
-def march_grid(field_h, field_v, bounds, cell, n_rows, n_cols, num_slices):
-	"""grid_h (with the reference's in-place row-end extension) and grid_hv before border extension."""
+def march_grid(field_h, field_v, bounds, cell, n_rows, n_cols, num_slices, noalloc=False):
+	"""grid_h (with the reference's in-place row-end extension) and grid_hv before border extension.
+	noalloc: through ogd_march_grid_noalloc (fixed device scratch, no allocation; at most 262144 nodes)."""
 	b, bp = _bounds(bounds)
 	grid_h = np.empty((n_rows, n_cols, 2), dtype=np.float32)
 	grid_hv = np.empty((n_rows, n_cols, 2), dtype=np.float32)
-	check(load().ogd_march_grid(
+	lib = load()
+	check((lib.ogd_march_grid_noalloc if noalloc else lib.ogd_march_grid)(
 		*_field_args(field_h), *_field_args(field_v), bp, int(cell), int(n_rows), int(n_cols),
 		int(num_slices), _ptr(grid_h), _ptr(grid_hv)))
 	return grid_h, grid_hv

@@ -23,6 +23,7 @@
 #include "ogd_common.h"
 #include "ogd_tri_dev.h"
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 namespace ogd {
@@ -228,6 +229,101 @@ static int check_field(const ogd_tri* inner, const ogd_tri* extra, const char* w
   return OGD_OK;
 }
 
+
+// ---- the march proper, on device buffers the caller provides (the library's block cache or the fixed scratch) --
+static int check_march_args(const ogd_tri* inner_h, const ogd_tri* extra_h, const ogd_tri* inner_v,
+                            const ogd_tri* extra_v, int s, int n_rows, int n_cols, int num_slices,
+                            const float* grid_h, const float* grid_hv) {
+  OGD_REQUIRE(grid_h && grid_hv, "null pointer");
+  OGD_REQUIRE(s >= 1 && n_rows >= 2 && n_cols >= 3, "bad grid %dx%d / cell %d (at least 2 rows, 3 columns)", n_rows,
+              n_cols, s);
+  OGD_REQUIRE((int64_t)n_rows * s < (1 << 24) && (int64_t)n_cols * s < (1 << 24), "grid too large for float32");
+  OGD_REQUIRE(num_slices >= 1, "num_slices %d", num_slices);
+  OGD_TRY(check_field(inner_h, extra_h, "field_h"));
+  OGD_TRY(check_field(inner_v, extra_v, "field_v"));
+  return OGD_OK;
+}
+
+// dgh, dhv: [n_rows][n_cols] float2; dlen: one float per column slice; dst: one MarchStatus.  All four are
+// overwritten; nothing is allocated here.
+static int march_grid_run(const FieldView& fh, const FieldView& fv, int s, int n_rows, int n_cols, int num_slices,
+                          float2* dgh, float2* dhv, float* dlen, MarchStatus* dst, float* grid_h, float* grid_hv) {
+  const size_t gb = (size_t)n_rows * n_cols * sizeof(float2);
+  // make_slices(n, k): ceil(n / k) columns per slice (ref: dewarp.py:170-173)
+  const int slice_len = (n_cols + num_slices - 1) / num_slices;
+  const int n_slices = (n_cols + slice_len - 1) / slice_len;
+  MarchStatus st0{INT_MAX, -1, 0.f, 0.f, 0.f, 0.f};
+  OGD_HIP(hipMemcpy(dst, &st0, sizeof st0, hipMemcpyHostToDevice));
+  OGD_HIP(hipMemsetAsync(dhv, 0, gb, nullptr));
+
+  hipLaunchKernelGGL(march_rows_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, nullptr, fh, n_rows, n_cols, s, dgh);
+  OGD_TRY(check_launch("march_rows_kernel"));
+  // the reference asserts on grid_h before it is modified (ref: dewarp.py:437); the row-end extension keeps
+  // NaNs NaN, so the check below on the final array is equivalent
+  // pieces of k = 3 nodes, stride k - 1: every piece that reaches the row end extends it once more
+  int n_tail = 0;
+  for (int i = 0; i < n_cols; i += 2)
+    if (i != 0 && i + 3 >= n_cols) ++n_tail;
+  hipLaunchKernelGGL(march_row_ends_kernel, dim3((n_rows + 62) / 64), dim3(64), 0, nullptr, n_rows, n_cols,
+                     (float)(n_cols * s), n_tail, dgh);
+  OGD_TRY(check_launch("march_row_ends_kernel"));
+  hipLaunchKernelGGL(march_rise_kernel, dim3(n_slices), dim3(256), 0, nullptr, dgh, n_rows, n_cols, slice_len, dlen);
+  OGD_TRY(check_launch("march_rise_kernel"));
+  hipLaunchKernelGGL(march_columns_kernel, dim3((n_cols + 3) / 4), dim3(256), 0, nullptr, fv, dgh, n_rows, n_cols,
+                     slice_len, dlen, dhv, dst);
+  OGD_TRY(check_launch("march_columns_kernel"));
+  MarchStatus st;
+  OGD_HIP(hipMemcpy(&st, dst, sizeof st, hipMemcpyDeviceToHost));
+  OGD_HIP(hipMemcpy(grid_h, dgh, gb, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < (size_t)n_rows * n_cols * 2; ++i)
+    if (std::isnan(grid_h[i])) return fail(OGD_ERR_ASSERT, "NaN in grid_h (node %zu)", i / 2);
+  if (st.fail_col != INT_MAX)
+    return fail(OGD_ERR_RUNTIME, "failed to find intersection for i=%d, n=%d, [%g %g] to [%g %g].",
+                st.fail_col % slice_len, std::min(slice_len, n_cols - st.fail_col / slice_len * slice_len),
+                (double)st.p0x, (double)st.p0y, (double)st.p1x, (double)st.p1y);
+  OGD_HIP(hipMemcpy(grid_hv, dhv, gb, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+// ---- ogd_march_grid_noalloc: the same march for callers that cannot allocate ---------------------------------
+// Its device buffers (both node grids, the slice ray lengths, the status record) live in ONE file-scope device
+// array that every GPU the library runs on holds from module load to process end (~4 MiB).  `scratch` below is
+// the host-side stand-in of that array, NOT a device address: host code only ever uses the per-device address
+// hipGetSymbolAddress returns for it (noalloc_scratch), and the kernels take that address as an argument
+// exactly as they take the block-cache buffers in ogd_march_grid.
+constexpr int NOALLOC_MAX_NODES = 1 << 18;  // n_rows * n_cols; a 6000 x 8000 page at cell 25 has ~80 k
+constexpr int NOALLOC_MAX_SLICES = 1024;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+
+struct MarchScratch {
+  float2 gh[NOALLOC_MAX_NODES];
+  float2 hv[NOALLOC_MAX_NODES];
+  float step_len[NOALLOC_MAX_SLICES];
+  MarchStatus status;
+};
+
+static __device__ __align__(256) unsigned char scratch[sizeof(MarchScratch)];
+
+static std::mutex g_scratch_mutex;
+static MarchScratch* g_scratch_ptr[NOALLOC_MAX_DEVICES];  // per device: each GPU has its own copy of the array
+
+// The calling thread's current device must be the one to run on (ensure_device() has seen to that).
+static int noalloc_scratch(MarchScratch** out) {
+  int dev = -1;
+  OGD_HIP(hipGetDevice(&dev));
+  OGD_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "device %d beyond the %d this entry point keeps scratch for", dev,
+              NOALLOC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    OGD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(OGD_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
+    g_scratch_ptr[dev] = static_cast<MarchScratch*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return OGD_OK;
+}
+
 }  // namespace ogd
 
 using namespace ogd;
@@ -263,17 +359,9 @@ int ogd_march_shape(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_
 int ogd_march_grid(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h, const ogd_tri* inner_v,
                    const ogd_tri* extra_v, double phi0_v, const double* bounds, int s, int n_rows, int n_cols,
                    int num_slices, float* grid_h, float* grid_hv) {
-  OGD_REQUIRE(grid_h && grid_hv, "null pointer");
-  OGD_REQUIRE(s >= 1 && n_rows >= 2 && n_cols >= 3, "bad grid %dx%d / cell %d (at least 2 rows, 3 columns)", n_rows,
-              n_cols, s);
-  OGD_REQUIRE((int64_t)n_rows * s < (1 << 24) && (int64_t)n_cols * s < (1 << 24), "grid too large for float32");
-  OGD_REQUIRE(num_slices >= 1, "num_slices %d", num_slices);
-  OGD_TRY(check_field(inner_h, extra_h, "field_h"));
-  OGD_TRY(check_field(inner_v, extra_v, "field_v"));
+  OGD_TRY(check_march_args(inner_h, extra_h, inner_v, extra_v, s, n_rows, n_cols, num_slices, grid_h, grid_hv));
   OGD_TRY(ensure_device());
-  const FieldView fh = field_view(inner_h, extra_h, phi0_h, bounds), fv = field_view(inner_v, extra_v, phi0_v, bounds);
   const size_t gb = (size_t)n_rows * n_cols * sizeof(float2);
-  // make_slices(n, k): ceil(n / k) columns per slice (ref: dewarp.py:170-173)
   const int slice_len = (n_cols + num_slices - 1) / num_slices;
   const int n_slices = (n_cols + slice_len - 1) / slice_len;
   DevBuf dgh, dhv, dlen, dst;
@@ -281,39 +369,26 @@ int ogd_march_grid(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h
   OGD_TRY(dhv.alloc(gb));
   OGD_TRY(dlen.alloc(n_slices * sizeof(float)));
   OGD_TRY(dst.alloc(sizeof(MarchStatus)));
-  MarchStatus st0{INT_MAX, -1, 0.f, 0.f, 0.f, 0.f};
-  OGD_HIP(hipMemcpy(dst.p, &st0, sizeof st0, hipMemcpyHostToDevice));
-  OGD_HIP(hipMemsetAsync(dhv.p, 0, gb, nullptr));
+  return march_grid_run(field_view(inner_h, extra_h, phi0_h, bounds), field_view(inner_v, extra_v, phi0_v, bounds), s,
+                        n_rows, n_cols, num_slices, dgh.as<float2>(), dhv.as<float2>(), dlen.as<float>(),
+                        dst.as<MarchStatus>(), grid_h, grid_hv);
+}
 
-  hipLaunchKernelGGL(march_rows_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, nullptr, fh, n_rows, n_cols, s,
-                     dgh.as<float2>());
-  OGD_TRY(check_launch("march_rows_kernel"));
-  // the reference asserts on grid_h before it is modified (ref: dewarp.py:437); the row-end extension keeps
-  // NaNs NaN, so the check below on the final array is equivalent
-  // pieces of k = 3 nodes, stride k - 1: every piece that reaches the row end extends it once more
-  int n_tail = 0;
-  for (int i = 0; i < n_cols; i += 2)
-    if (i != 0 && i + 3 >= n_cols) ++n_tail;
-  hipLaunchKernelGGL(march_row_ends_kernel, dim3((n_rows + 62) / 64), dim3(64), 0, nullptr, n_rows, n_cols,
-                     (float)(n_cols * s), n_tail, dgh.as<float2>());
-  OGD_TRY(check_launch("march_row_ends_kernel"));
-  hipLaunchKernelGGL(march_rise_kernel, dim3(n_slices), dim3(256), 0, nullptr, dgh.as<float2>(), n_rows, n_cols,
-                     slice_len, dlen.as<float>());
-  OGD_TRY(check_launch("march_rise_kernel"));
-  hipLaunchKernelGGL(march_columns_kernel, dim3((n_cols + 3) / 4), dim3(256), 0, nullptr, fv, dgh.as<float2>(),
-                     n_rows, n_cols, slice_len, dlen.as<float>(), dhv.as<float2>(), dst.as<MarchStatus>());
-  OGD_TRY(check_launch("march_columns_kernel"));
-  MarchStatus st;
-  OGD_HIP(hipMemcpy(&st, dst.p, sizeof st, hipMemcpyDeviceToHost));
-  OGD_HIP(hipMemcpy(grid_h, dgh.p, gb, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < (size_t)n_rows * n_cols * 2; ++i)
-    if (std::isnan(grid_h[i])) return fail(OGD_ERR_ASSERT, "NaN in grid_h (node %zu)", i / 2);
-  if (st.fail_col != INT_MAX)
-    return fail(OGD_ERR_RUNTIME, "failed to find intersection for i=%d, n=%d, [%g %g] to [%g %g].",
-                st.fail_col % slice_len, std::min(slice_len, n_cols - st.fail_col / slice_len * slice_len),
-                (double)st.p0x, (double)st.p0y, (double)st.p1x, (double)st.p1y);
-  OGD_HIP(hipMemcpy(grid_hv, dhv.p, gb, hipMemcpyDeviceToHost));
-  return OGD_OK;
+int ogd_march_grid_noalloc(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h, const ogd_tri* inner_v,
+                           const ogd_tri* extra_v, double phi0_v, const double* bounds, int s, int n_rows,
+                           int n_cols, int num_slices, float* grid_h, float* grid_hv) {
+  OGD_TRY(check_march_args(inner_h, extra_h, inner_v, extra_v, s, n_rows, n_cols, num_slices, grid_h, grid_hv));
+  OGD_REQUIRE((int64_t)n_rows * n_cols <= NOALLOC_MAX_NODES,
+              "ogd_march_grid_noalloc: %d x %d nodes exceed the fixed scratch of %d nodes; use ogd_march_grid", n_rows,
+              n_cols, NOALLOC_MAX_NODES);
+  const int slice_len = (n_cols + num_slices - 1) / num_slices;
+  OGD_REQUIRE((n_cols + slice_len - 1) / slice_len <= NOALLOC_MAX_SLICES,
+              "ogd_march_grid_noalloc: more than %d column slices; use ogd_march_grid", NOALLOC_MAX_SLICES);
+  OGD_TRY(ensure_device());
+  MarchScratch* sc = nullptr;
+  OGD_TRY(noalloc_scratch(&sc));
+  return march_grid_run(field_view(inner_h, extra_h, phi0_h, bounds), field_view(inner_v, extra_v, phi0_v, bounds), s,
+                        n_rows, n_cols, num_slices, sc->gh, sc->hv, sc->step_len, &sc->status, grid_h, grid_hv);
 }
 
 }  // extern "C"
