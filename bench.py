@@ -14,6 +14,14 @@ batch (weak scaling, no collective on the data path).
 
 The host-side grid construction (marching the node grid, Qhull) is set-up, as it is in the reference,
 where the dewarp stage writes dewarp.zip once and every later stage only re-runs K1a + K2.
+
+`--gpus N` (N > 1) without a launcher starts N ranks itself (`python -m torch.distributed.run ...` as a child
+process, before this process touches a GPU) — the plain command the driver's contract names always measures N
+ranks.  `value` is the device-resident rate at every N (inputs in HBM when the timed region starts); the
+PCIe-inclusive rate of BASELINE.json configs[2] (page jobs from a pinned host ring -> H2D -> fused dewarp + K3 ->
+D2H on three streams per GPU) is measured after the timed steps under the same barrier /
+max-over-ranks contract and reported beside it as `pipeline` — it shows the host-side limiter (PCIe, DRAM) that
+the resident loop cannot.
 """
 
 import argparse
@@ -57,6 +65,8 @@ def parse_args():
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--pages", type=int, default=64, help="pages per batch and GPU")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-pipeline", action="store_true", help="skip the host-ring pipeline leg (configs[2])")
+	ap.add_argument("--pipeline-jobs", type=int, default=0, help="page jobs per GPU in the pipeline leg (0 = 2 x pages)")
 	ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
 	ap.add_argument("--harness-selftest", action="store_true",
 		help="CPU / gloo run of the N-rank timing harness with a sleeping step (tests/test_multi.py)")
@@ -215,6 +225,110 @@ def cpu_baseline(wl, threads, budget_s=12.0):
 			n, spent, t_pix, threads, len(wl["polys"][0]["rings"]), t_pts))
 
 
+def bind_to_gpu_numa_node(torch, local_rank):
+	"""Pin this rank's threads (and with them the pinned host ring it is about to allocate: first touch) to the
+	NUMA node its GPU hangs off, so that eight ranks do not stage through one socket's DRAM.  Best effort: any
+	failure leaves the affinity alone.  Returns the node number or None."""
+	try:
+		hip = ctypes.CDLL("libamdhip64.so")
+		buf = ctypes.create_string_buffer(64)
+		if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) != 0:
+			return None
+		bus = buf.value.decode().lower()
+		node = int(Path("/sys/bus/pci/devices/%s/numa_node" % bus).read_text())
+		if node < 0:
+			return None
+		cpus = set()
+		for part in Path("/sys/devices/system/node/node%d/cpulist" % node).read_text().strip().split(","):
+			a, _, b = part.partition("-")
+			cpus.update(range(int(a), int(b or a) + 1))
+		cpus &= os.sched_getaffinity(0)
+		if not cpus:
+			return None
+		os.sched_setaffinity(0, cpus)
+		return node
+	except Exception:
+		return None
+
+
+def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, slots=3):
+	"""BASELINE.json configs[2] per GPU: `n_jobs` page jobs drawn by cycling the batch's
+	pages from a PINNED HOST ring -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + the page's contour rings (K3) ->
+	D2H of the dewarped page and the warped contours, on three streams (upload / kernels / download) with
+	`slots` device slots.  The last job's page is checked against the resident path's output.  Returns
+	(elapsed seconds of this rank, bytes up, bytes down)."""
+	W, H = PAGE
+	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
+	n_pages = wl["pages"].shape[0]
+	dev = wl["pages"].device
+	host_in = torch.empty((n_pages, H, W), dtype=torch.uint8, pin_memory=True)
+	host_in.copy_(wl["pages"])
+	host_out = torch.empty((slots + 1, Hd, Wd), dtype=torch.uint8, pin_memory=True)
+	max_pts = max(p["n"] for p in wl["polys"])
+	host_pts = torch.empty((slots + 1, max_pts, 2), dtype=torch.float64, pin_memory=True)
+	d_in = torch.empty((slots, H, W), dtype=torch.uint8, device=dev)
+	d_out = torch.empty((slots, Hd, Wd), dtype=torch.uint8, device=dev)
+	s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+	ev_in = [torch.cuda.Event() for _ in range(slots)]
+	ev_k = [torch.cuda.Event() for _ in range(slots)]
+	ev_out = [torch.cuda.Event() for _ in range(slots)]
+	kstream = ctypes.c_void_p(s_k.cuda_stream)
+
+	def run(n):
+		for j in range(n):
+			p, sl, ho = j % n_pages, j % slots, j % (slots + 1)
+			wp, poly = wl["warps"][p % len(wl["warps"])], wl["polys"][p]
+			with torch.cuda.stream(s_in):
+				s_in.wait_event(ev_k[sl])  # the slot's previous kernel has read d_in[sl]
+				d_in[sl].copy_(host_in[p], non_blocking=True)
+				ev_in[sl].record(s_in)
+			s_k.wait_event(ev_in[sl])
+			s_k.wait_event(ev_out[sl])  # the slot's previous download has read d_out[sl] / the page's contours
+			check(lib.ogd_dewarp_u8_dev(
+				d_in[sl].data_ptr(), H, W, 1, W, wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0,
+				d_out[sl].data_ptr(), Wd, 1, kstream))
+			check(lib.ogd_tri_eval_ragged_dev(
+				wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
+				poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), kstream))
+			ev_k[sl].record(s_k)
+			with torch.cuda.stream(s_out):
+				s_out.wait_event(ev_k[sl])
+				host_out[ho].copy_(d_out[sl], non_blocking=True)
+				host_pts[ho, :poly["n"]].copy_(poly["out"], non_blocking=True)
+				ev_out[sl].record(s_out)
+		torch.cuda.synchronize()
+
+	run(2 * slots)
+	barrier()
+	t0 = time.perf_counter()
+	run(n_jobs)
+	elapsed = time.perf_counter() - t0
+	barrier()
+	last = (n_jobs - 1) % n_pages
+	if not torch.equal(host_out[(n_jobs - 1) % (slots + 1)], wl["outs"][last].cpu()):
+		raise SystemExit("bench: pipeline output differs from the resident path")
+	up = n_jobs * H * W
+	down = n_jobs * Hd * Wd + sum(wl["polys"][j % n_pages]["n"] for j in range(n_jobs)) * 16
+	return elapsed, up, down
+
+
+def launch_ranks(n):
+	"""`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process
+	and leave with its exit code.  Called before this process has touched a GPU (nothing is re-exec'ed)."""
+	import socket
+	import subprocess
+	with socket.socket() as sock:
+		sock.bind(("127.0.0.1", 0))
+		port = sock.getsockname()[1]
+	cmd = [
+		sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+		"--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+	env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	env.setdefault("OMP_NUM_THREADS", "2")
+	return subprocess.call(cmd, env=env, cwd=str(ROOT))
+
+
 def timed_steps(step, steps, warmup, sync, dist, world, device, between=None):
 	"""The timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier +
 	device synchronisation on both sides; returns the MAX over ranks of the elapsed seconds."""
@@ -272,7 +386,11 @@ def main():
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
-	if world != args.gpus and world > 1:
+	if args.gpus < 1:
+		raise SystemExit("--gpus must be >= 1")
+	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		sys.exit(launch_ranks(args.gpus))  # no launcher: be one (child process; this one never touches a GPU)
+	if world != args.gpus:
 		raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 	if args.harness_selftest:
 		return harness_selftest(args, rank, world)
@@ -283,6 +401,7 @@ def main():
 
 	if not torch.cuda.is_available():
 		raise SystemExit("bench.py needs a GPU (no CPU fallback exists on the product path)")
+	numa_node = bind_to_gpu_numa_node(torch, local_rank) if world > 1 else None
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
 	_shim.init(local_rank)
@@ -307,6 +426,21 @@ def main():
 		t = torch.tensor([fused_mps], dtype=torch.float64, device=dev)
 		dist.all_reduce(t, op=dist.ReduceOp.SUM)
 		fused_mps = float(t.item())
+
+	pipeline = None
+	if not args.no_pipeline:
+		def barrier():
+			torch.cuda.synchronize()
+			if world > 1:
+				dist.barrier()
+				torch.cuda.synchronize()
+		n_jobs = args.pipeline_jobs or 2 * args.pages
+		p_elapsed, up, down = pipeline_leg(torch, lib, check, wl, n_jobs, barrier)
+		t = torch.tensor([p_elapsed], dtype=torch.float64, device=dev)
+		if world > 1:
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		p_elapsed = float(t.item())
+		pipeline = dict(n_jobs=n_jobs, elapsed=p_elapsed, up=up, down=down)
 
 	Hd, Wd = wl["Hd"], wl["Wd"]
 	W, H = PAGE
@@ -353,6 +487,17 @@ def main():
 				"avg_launch_ms": round(k2_ms, 4),
 			},
 		}
+		if pipeline is not None:
+			pe = pipeline["elapsed"]
+			line["pipeline"] = {
+				"what": "configs[2] (SURVEY 8d ii): %d page jobs per GPU cycled from a pinned host ring of the batch's %d pages -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + K3 -> D2H of page and contours, 3 streams / 3 device slots per GPU; barrier + max over ranks; PCIe-inclusive, never `value`" % (
+					pipeline["n_jobs"], args.pages),
+				"value": round(world * pipeline["n_jobs"] * Hd * Wd / 1e6 / pe, 1), "unit": "MP/s",
+				"ms_per_page_per_gpu": round(pe / pipeline["n_jobs"] * 1e3, 4),
+				"h2d_GBs_per_gpu": round(pipeline["up"] / pe / 1e9, 2),
+				"d2h_GBs_per_gpu": round(pipeline["down"] / pe / 1e9, 2),
+				"numa_node_rank0": numa_node,
+			}
 		if not args.no_cpu_baseline and world == 1:
 			threads = args.cpu_threads or min(16, os.cpu_count() or 1)
 			line["cpu_baseline"] = cpu_baseline(wl, threads)

@@ -86,6 +86,21 @@ class DatabaseMutex:
 				conn.execute("COMMIT")
 		run_db_operation(perform)
 
+	def unlock_pid(self, pid):
+		"""Drops every lock a (dead) process of THIS machine still holds; the stage's parent calls it for a
+		worker that was killed before it could unlock."""
+		def perform():
+			with self._connect() as conn:
+				conn.execute("BEGIN EXCLUSIVE")
+				conn.execute("DELETE FROM mutex WHERE pid = ?", (int(pid),))
+				conn.execute("COMMIT")
+		run_db_operation(perform)
+
+	def held(self):
+		"""[(path, processor, pid)] of all current locks (diagnostics, tests)."""
+		with self._connect() as conn:
+			return list(conn.execute("SELECT path, processor, pid FROM mutex ORDER BY path"))
+
 	@contextmanager
 	def lock(self, processor, paths):
 		success = self.try_lock(processor, paths)

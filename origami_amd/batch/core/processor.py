@@ -343,6 +343,17 @@ class Processor:
 			if failed and w.is_alive():
 				w.terminate()
 			w.join(timeout=30)
+		# A worker killed by a signal (GPU fault -> abort, SIGSEGV, the kernel's OOM killer) runs neither its
+		# `except` nor its `finally`: it reports nothing, its chunk stays undone and its lock rows stay behind.
+		for r, w in enumerate(workers):
+			if w.exitcode not in (0, None):
+				logging.error("worker %d (pid %s, GPU %s) died with exit code %s." % (r, w.pid, devices[r], w.exitcode))
+				failed = True
+				if isinstance(self._mutex, DatabaseMutex) and w.pid is not None:
+					self._mutex.unlock_pid(w.pid)
+		if not failed and (alive > 0 or done < len(queued)):
+			logging.error("workers ended with %d of %d pages unaccounted for." % (len(queued) - done, len(queued)))
+			failed = True
 		if failed:
 			sys.exit(1)
 

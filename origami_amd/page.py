@@ -82,7 +82,10 @@ class Page:
 		return self.dewarper.dewarped_jpeg(quality)
 
 	def _on_device_format(self):
-		return (self._opened is not None and self._opened.format == "JPEG" and self._opened.mode == "L"
+		# "L": one-component scans; "RGB": what PIL calls a three-component (JFIF YCbCr) scan.  Whether the device
+		# decoder covers the file (baseline, JFIF, interleaved ...) is ogd_jpeg_info's decision; Adobe / CMYK /
+		# progressive files come back None from the decode call and go through PIL.
+		return (self._opened is not None and self._opened.format == "JPEG" and self._opened.mode in ("L", "RGB")
 			and bool(getattr(self._opened, "filename", None)))
 
 	def size(self, dewarped):

@@ -24,6 +24,9 @@ class FakeDewarpProcessor(Processor):
 	def process(self, page_path, warped, output):
 		if page_path.stem.startswith("bad"):
 			raise RuntimeError("synthetic failure")
+		if page_path.stem.startswith("kill"):  # what a GPU fault / the OOM killer does to a worker: no unwinding
+			import signal
+			os.kill(os.getpid(), signal.SIGKILL)
 		info = dict(pid=os.getpid(), rank=self._rank, device=os.environ.get("OGD_DEVICE"))
 		rendezvous = os.environ.get("FAKE_STAGE_RENDEZVOUS")  # "<dir>:<n>": hold the first page until n workers run
 		if rendezvous:

@@ -145,3 +145,17 @@ def test_two_gpu_workers_share_one_queue(tmp_path, lock, monkeypatch):
 	assert set(seen) == {0, 1}  # both workers took part (9 pages -> chunks of 2)
 	assert all(len(pids) == 1 for pids in seen.values())
 	assert FakeDewarpProcessor(options())._build_queue(tmp_path) == []
+
+
+def test_a_worker_killed_by_a_signal_fails_the_stage_and_frees_its_locks(tmp_path):
+	"""A spawned worker that dies without unwinding (SIGKILL here; a GPU fault's abort, SIGSEGV or the OOM killer
+	in the field) sends no message: the stage must still end non-zero, and the lock rows the dead worker held
+	must be gone so that a re-run can take its pages at once."""
+	make_pages(tmp_path, 2, prefix="kill")
+	make_pages(tmp_path, 4, prefix="page")
+	proc = FakeDewarpProcessor(options(gpus=2, devices="0,1", lock_strategy="DB", alive=30))
+	with pytest.raises(SystemExit) as e:
+		proc.traverse(tmp_path)
+	assert e.value.code == 1
+	assert not (tmp_path / "kill0000.out" / "dewarp.zip").exists()
+	assert DatabaseMutex(tmp_path / "origami.lock.db", timeout=5).held() == []

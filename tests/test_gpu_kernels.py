@@ -245,9 +245,12 @@ def test_tri_rasterize_equals_point_queries(gpu):
 	np.testing.assert_array_equal(dense.ravel(), fac.interpolator(q))
 
 
-def test_rings_self_cross_matches_host_geometry(gpu):
-	"""ogd_rings_self_cross (wavefront per ring) against the numpy restatement in origami_amd/geometry.py:
-	simple rings, bow-ties, rings that touch themselves at a vertex or along an edge, tiny rings."""
+def test_rings_self_cross_matches_the_exact_reference(gpu):
+	"""ogd_rings_self_cross (wavefront per ring, fp64 orientation signs) against oracle/rings.py — an independent
+	O(n^2) double loop in exact rational arithmetic that shares no code with the product — and, as a second
+	opinion, the product's own numpy form: simple rings, bow-ties, rings that touch themselves at a vertex or
+	along an edge, tiny rings."""
+	from oracle import rings as orings
 	from origami_amd import geometry
 	rng = np.random.default_rng(42)
 	rings = synth.polygon_rings(rng, (3000, 4000), 300, mu=30)
@@ -261,9 +264,10 @@ def test_rings_self_cross_matches_host_geometry(gpu):
 	rings.append(np.array([[0, 0], [1, 1], [0, 0]], dtype=np.float64))  # degenerate: two segments
 	rings.append(np.array([[0, 0], [4, 0], [4, 4], [0, 4], [0, 0]], dtype=np.float64))
 	got = gpu.rings_self_cross(rings)
-	want = np.array([geometry._segments_cross(r) for r in rings])
+	want = np.array([orings.ring_self_crosses(r) for r in rings])
 	assert got.dtype == bool and got.shape == want.shape
 	np.testing.assert_array_equal(got, want)
+	np.testing.assert_array_equal(np.array([geometry._segments_cross(r) for r in rings]), want)
 	assert want[:300].sum() == 0 and want[300:400].sum() > 50
 	assert len(gpu.rings_self_cross([])) == 0
 

@@ -66,6 +66,45 @@ def test_march_broadsheet_page(gpu):
 	assert np.abs(hv - want.hv).max() < 1e-3
 
 
+def test_march_heavy_warp_broadsheet_page(gpu):
+	"""The grid half of configs[4]: a heavily warped 6000 x 8000 page (A = B = 0.12 rad, about 7 degrees) with
+	2000 horizontal and 3000 vertical flow samples through Grid.create, against the oracle's walk: identical
+	shape, every node within 1e-3 px (ref: origami/core/dewarp.py:421-493)."""
+	size = (6000, 8000)
+	rng = np.random.default_rng(5)
+	h, v, oh, ov = _pair(rng, size, 2000, 3000, a=0.12, b=0.12, f1=1, f2=2)
+	grid = Grid.create(_page(size), h, v, grid_res=25)
+	want = odw.Grid.create(size, oh, ov, grid_res=25)
+	hv = grid.points("sample")
+	assert hv.shape == want.hv.shape == (341, 255, 2)
+	assert np.abs(hv - want.hv).max() < 1e-3
+
+
+@pytest.mark.parametrize("seed,a,f", [(8, 0.4, 3), (7, 0.4, 2), (8, 0.3, 3)])
+def test_march_rays_that_miss_the_next_row_retry_on_later_rows(gpu, monkeypatch, seed, a, f):
+	"""Warps so strong (0.3-0.4 rad at 3 periods per page) that rays miss row gy + 1 of grid_h and meet a later
+	row — the retry loop of ShapelyBatchIntersections.__call__ (ref: origami/core/dewarp.py:243-255).  The
+	oracle's walk counts its misses, so the test proves the path was taken; shapes identical, nodes < 1e-3 px."""
+	size = (1500, 2000)
+	rng = np.random.default_rng(seed)
+	h, v, oh, ov = _pair(rng, size, 500, 700, a=a, b=a, f1=f, f2=f)
+	misses = [0]
+	plain = odw._segment_hits
+
+	def counting(p0, p1, row):
+		hits = plain(p0, p1, row)
+		misses[0] += not hits
+		return hits
+
+	monkeypatch.setattr(odw, "_segment_hits", counting)
+	want = odw.Grid.create(size, oh, ov, grid_res=25)
+	assert misses[0] > 0, "this warp no longer exercises the retry path"
+	grid = Grid.create(_page(size), h, v, grid_res=25)
+	hv = grid.points("sample")
+	assert hv.shape == want.hv.shape
+	assert np.abs(hv - want.hv).max() < 1e-3
+
+
 def test_constant_fields_give_a_regular_grid(gpu):
 	"""<= 2 samples per direction: constant angles 0 and pi/2 (ref: dewarp.py:112-113, 318-326)."""
 	size = (500, 400)

@@ -75,6 +75,59 @@ def test_dewarp_stage_matches_oracle(gpu, tmp_path):
 	np.testing.assert_array_equal(np.array(page.dewarped), want)
 
 
+def test_dewarp_stage_config0_full_size(gpu, tmp_path):
+	"""BASELINE.json configs[0] at its stated workload: the `dewarp` CLI on ONE 2400 x 3400
+	gray page with 300 horizontal / 500 vertical flow samples, 60 region polygons, 12 separator line strings and a
+	dummy segment.zip (1280 x 2400 label maps), checked against the oracle like the scaled-down test above."""
+	rng = np.random.default_rng(1000)
+	size = (2400, 3400)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=300, n_v=500, n_regions=60, n_separators=12,
+		label_size=(1280, 2400), warp=synth.Warp(size, 0.03, 0.025, 1, 2))
+	out = page_path.with_suffix(".out")
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	assert sorted(p.name for p in out.iterdir()) == [
+		"contours.0.zip", "contours.1.zip", "dewarp.zip", "flow.zip", "runtime.json", "segment.zip"]
+	assert json.loads((out / "runtime.json").read_text())["origami.batch.detect.dewarp"]["status"] == "COMPLETED"
+
+	with zipfile.ZipFile(out / "dewarp.zip") as zf:
+		assert zf.namelist() == ["data.npy", "meta.json"]
+		meta = json.loads(zf.read("meta.json"))
+		data = np.load(io.BytesIO(zf.read("data.npy")))
+	assert meta == dict(version=1, cell=25, shape=list(data.shape)) and data.dtype == np.float32
+	with zipfile.ZipFile(out / "flow.zip") as zf:
+		oh, ov = odw.Samples.open(zf, "h"), odw.Samples.open(zf, "v")
+	assert len(oh) == 300 and len(ov) == 500
+	ogrid = odw.Grid.create(size, oh, ov, grid_res=25)
+	assert data.shape == ogrid.hv.shape and data.shape[0] >= 137 and data.shape[1] >= 97
+	assert np.abs(data - ogrid.hv).max() < 1e-3
+
+	with zipfile.ZipFile(out / "contours.0.zip") as z0, zipfile.ZipFile(out / "contours.1.zip") as z1:
+		names = z0.namelist()
+		assert sum(n.startswith("regions/TEXT/") for n in names) == 60
+		assert sum(n.startswith("separators/V/") and n.endswith(".wkt") for n in names) == 12
+		assert sorted(z1.namelist()) == sorted(names) and z1.namelist()[0] == "meta.json"
+		assert z1.read("separators/V/meta.json") == z0.read("separators/V/meta.json")
+		tf = odw.Grid(data, 25).transformer
+		for name in names:
+			if not name.endswith(".wkt"):
+				continue
+			g0 = geometry.parse_wkt(z0.read(name).decode("utf8"))
+			g1 = geometry.parse_wkt(z1.read(name).decode("utf8"))
+			assert g1.geom_type == g0.geom_type and len(g1.rings) == len(g0.rings)
+			for want, got in zip(odw.transform_rings(tf, g0.rings), g1.rings):
+				assert np.abs(want - got).max() < 1e-3
+				# "warped integer contours bit-exact": rounded coordinates agree off the .5 boundary
+				off_tie = np.abs(want - np.floor(want) - 0.5) > 1e-4
+				assert np.array_equal(np.round(want)[off_tie], np.round(got)[off_tie])
+
+	# the page every later stage sees (ref: io.py:275-280, page.py:86-88), whole page bit-exact
+	page = Page(page_path, Grid.open(out / "dewarp.zip"))
+	want = odw.dewarped(np.array(page.warped), odw.Grid(data, 25), threads=8)
+	np.testing.assert_array_equal(np.array(page.dewarped), want)
+
+
 def test_page_without_regions_is_skipped_silently(gpu, tmp_path):
 	rng = np.random.default_rng(12)
 	page_path = synth.write_page_dir(tmp_path, "empty", rng, size=(300, 400), n_h=20, n_v=20, n_regions=0, n_separators=1, label_size=(160, 213))
@@ -256,7 +309,7 @@ def test_dewarped_image_stage_on_a_jpeg_scan(gpu, tmp_path):
 	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()
 
 
-def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tmp_path):
+def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tmp_path, monkeypatch):
 	"""A colour scan (JFIF YCbCr 4:2:0, a restart marker per MCU row): the reference opens it with
 	`.convert("L")` (origami/core/page.py:82-84); here it is decoded to "L" on the device, and the stage's output is
 	the file PIL writes for the oracle's dewarp of PIL's own "L" pixels."""
@@ -273,11 +326,29 @@ def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tm
 	assert PIL.Image.open(page_path).mode == "RGB"
 	assert gpu.jpeg_info(page_path.read_bytes())[2:] == (3, True)
 	pixels = np.array(PIL.Image.open(page_path).convert("L"))
+	# the device decoder must be the one that runs (not PIL compared with PIL): count its calls and results
+	calls = dict(decode=0, fused=0)
+	plain_decode, plain_fused = gpu.jpeg_decode_gray, gpu.jpeg_dewarp_jpeg_gray
+
+	def decode(data):
+		out = plain_decode(data)
+		calls["decode"] += out is not None
+		return out
+
+	def fused(*args, **kwargs):
+		out = plain_fused(*args, **kwargs)
+		calls["fused"] += out is not None
+		return out
+
+	monkeypatch.setattr(gpu, "jpeg_decode_gray", decode)
+	monkeypatch.setattr(gpu, "jpeg_dewarp_jpeg_gray", fused)
 	assert np.array_equal(np.array(Page(page_path).warped), pixels)  # device decode == PIL decode + convert
+	assert calls["decode"] == 1
 	out = page_path.with_suffix(".out")
 	assert CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"]).exit_code == 0
 	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
 	assert res.exit_code == 0, res.output
+	assert calls["fused"] == 1  # scan file in -> dewarped JPEG out, all on the device
 	nodes = Grid.open(out / "dewarp.zip").points("sample")
 	want = PIL.Image.fromarray(odw2.dewarped(pixels, odw2.Grid(nodes, 25)))
 	ref = io.BytesIO()

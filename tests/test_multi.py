@@ -35,3 +35,23 @@ def test_harness_world_1_and_2():
 	assert two["n_gpus"] == 2
 	# rank 1 sleeps 20 ms per step: the harness reports the slowest rank
 	assert 20.0 <= two["ms_per_step"] < 45.0
+
+
+def test_plain_command_with_gpus_2_launches_two_ranks():
+	"""`python bench.py --gpus 2 ...` WITHOUT torchrun (WORLD_SIZE unset): bench.py starts the two ranks itself
+	as a child process and the one JSON line says n_gpus 2 — a scaling run can never silently measure one rank."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+	env.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+	cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--harness-selftest", "--steps", "4", "--warmup", "1"]
+	out = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+	assert out.returncode == 0, out.stderr.decode()[-2000:]
+	lines = [json.loads(l) for l in out.stdout.decode().splitlines() if l.startswith("{")]
+	assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 4
+	assert 20.0 <= lines[0]["ms_per_step"] < 45.0
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+	env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+	cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--harness-selftest"]
+	out = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+	assert out.returncode != 0 and b"WORLD_SIZE" in out.stderr

@@ -262,3 +262,110 @@ def test_transformer_inverts_the_grid():
 	err = np.hypot(x - xs.ravel(), y - ys.ravel())
 	# piecewise-linear over Delaunay triangles vs bilinear over cells offset by half a cell
 	assert np.median(err) < 0.5 and err.max() < 3
+
+
+# ---- pins that exist in the build container: sympy (corner projection), SciPy 1.7.1 (Qhull diagonals) ------
+
+def _sympy_corner_value(cx, cy, p1, p2):
+	"""The corner value exactly as the reference computes it (origami/core/lingrid.py:115-128), through sympy."""
+	import sympy.geometry
+	line = sympy.geometry.Line(sympy.geometry.Point(*p1[:2]), sympy.geometry.Point(*p2[:2]))
+	p = line.projection(sympy.geometry.Point(cx, cy))
+	p = p.evalf()
+	p = np.array([p.x, p.y], dtype=np.float64)
+	d = np.linalg.norm(p - p1[:2])
+	d_total = np.linalg.norm(p2[:2] - p1[:2])
+	x = d / d_total
+	return (1 - x) * p1[2:] + x * p2[2:]
+
+
+def test_corner_projection_is_pinned_by_sympy():
+	"""Box._add_corner of the product and BorderBox._corner of the oracle restate sympy's
+	Line.projection(...).evalf() in closed form (exact rationals of the doubles).  sympy IS importable here
+	(1.14; the reference pins 1.5.1), so both are checked against the call the reference makes.  sympy.Point
+	turns floats into rationals through their 15-digit decimal form, so its projection is that of points moved
+	by <= 5e-16 relative: the bar is 1e-12 relative on the corner value (observed ~1e-15), scalar and vector."""
+	pytest.importorskip("sympy")
+	from origami_amd import lingrid as plin
+	rng = np.random.default_rng(77)
+	worst = 0.0
+	for k in range(12):
+		W, H = rng.uniform(300, 8000, size=2)
+		nv = 1 + k % 2
+		# a point on the left border and one on the top border, as _nearest_to_corner hands them over
+		p1 = np.hstack([[-1.0, rng.uniform(0, H)], rng.normal(0, 1 if nv == 1 else 3000, size=nv)])
+		p2 = np.hstack([[rng.uniform(0, W), -1.0], rng.normal(0, 1 if nv == 1 else 3000, size=nv)])
+		want = _sympy_corner_value(-1.0, -1.0, p1, p2)
+		box = plin.Box(0, 0, W, H)
+		box._add_corner(-1.0, -1.0, p1, p2)
+		got_product = box._corners[(-1.0, -1.0)]
+		obox = olin.BorderBox(0, 0, W, H)
+		obox._corner(-1.0, -1.0, p1, p2)
+		got_oracle = obox.corners[(-1.0, -1.0)]
+		np.testing.assert_array_equal(got_product, got_oracle)
+		scale = max(np.abs(p1[2:]).max(), np.abs(p2[2:]).max())
+		err = np.abs(got_oracle - want).max() / scale
+		worst = max(worst, err)
+		assert err < 1e-12
+	print("corner projection vs sympy: worst relative difference %.2e" % worst)
+
+
+def test_qhull_diagonals_scipy_171_vs_current():
+	"""tests/golden/scipy171.npz holds Qhull's triangulations of every Delaunay input of the golden fixtures as
+	SciPy 1.7.1 builds them (generator: tests/golden/make_scipy171.py, run under /opt/conda/bin/python3.9; the
+	reference pins 1.3.1).  The current SciPy must give the same hull, and the same triangles except where four
+	nodes are cocircular to rounding — flipped diagonals are counted and printed; the interpolant across a
+	flipped quad differs by O(curvature * cell^2), covered by the 1e-3 px bar of the transformer tests."""
+	import scipy.spatial
+	z = golden("scipy171")
+	assert str(z["scipy_version"]) == "1.7.1"
+	report = {}
+	for name in ("field_n64", "grid_h", "grid_v", "transformer", "transformer_cfg0"):
+		pts = z[name + "_points"]
+		hull = scipy.spatial.ConvexHull(pts).vertices
+		# same cyclic order up to the starting vertex
+		old = list(z[name + "_hull"])
+		assert sorted(hull) == sorted(old)
+		k = old.index(hull[0])
+		assert old[k:] + old[:k] == list(hull)
+		# the extrapolation set is built from the hull: identical point sets under both versions
+		fac = olin.Factory(list(pts), list(np.zeros(len(pts))), (pts[:, 0].min(), pts[:, 1].min(), pts[:, 0].max(), pts[:, 1].max())) \
+			if name.startswith("transformer") else None
+		if fac is not None:
+			np.testing.assert_array_equal(fac.extra_pts, z[name + "_extra_points"])
+		for part, p in (("inner", pts), ("extra", z[name + "_extra_points"])):
+			new = {tuple(t) for t in np.sort(scipy.spatial.Delaunay(p).simplices, axis=1)}
+			was = {tuple(t) for t in z["%s_%s" % (name, part)]}
+			assert len(new) == len(was)
+			report["%s_%s" % (name, part)] = (len(was - new), len(was))
+	print("Qhull triangles that differ between SciPy 1.7.1 and %s: %s" % (scipy.__version__, report))
+	# scattered flow samples are in general position: no flips there
+	for key in ("field_n64_inner", "grid_h_inner", "grid_v_inner"):
+		assert report[key][0] == 0, report
+	# a marched lattice is nearly cocircular everywhere: flips may happen, but stay a small minority
+	for key in ("transformer_inner", "transformer_cfg0_inner"):
+		assert report[key][0] <= 0.02 * report[key][1], report
+
+
+def test_ring_self_cross_reference_known_answers():
+	"""oracle/rings.py (exact, O(n^2)) on hand-derived cases: simple, bow-tie, self-touching at a vertex,
+	T-touch of a vertex on an edge, a spike (collinear overlap), the closing-segment adjacency."""
+	from oracle import rings as orings
+	square = [(0, 0), (4, 0), (4, 4), (0, 4), (0, 0)]
+	bowtie = [(0, 0), (2, 2), (2, 0), (0, 2), (0, 0)]  # edges cross at (1, 1)
+	touch = [(0, 0), (0, 2), (1, 1), (2, 2), (2, 0), (1, 1), (0, 0)]  # the shapely manual's bow-tie: vertex met twice
+	t_touch = [(0, 0), (4, 0), (4, 4), (2, 0), (0, 4), (0, 0)]  # vertex (2, 0) lies on the first edge
+	spike = [(0, 0), (4, 0), (4, 4), (4, 6), (4, 4), (0, 4), (0, 0)]  # out and back along the same line
+	tri = [(0, 0), (1, 0), (0, 1), (0, 0)]
+	assert not orings.ring_self_crosses(square)
+	assert not orings.ring_self_crosses(tri)
+	assert orings.ring_self_crosses(bowtie)
+	assert orings.ring_self_crosses(touch)
+	assert orings.ring_self_crosses(t_touch)
+	assert not orings.ring_self_crosses(spike[:4] + spike[5:])
+	# a spike visits (4, 4) twice: the segment arriving there first and the one returning from the tip are not
+	# adjacent and share that point
+	assert orings.ring_self_crosses(spike)
+	# a crossing 1e-9 away from a vertex is still found (exact arithmetic)
+	near = [(0, 0), (2, 2), (2, 0), (1e-9, 2), (0, 0)]
+	assert orings.ring_self_crosses(near)
