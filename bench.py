@@ -251,12 +251,15 @@ def bind_to_gpu_numa_node(torch, local_rank):
 		return None
 
 
-def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, slots=3):
+def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, streams, slots=3):
 	"""BASELINE.json configs[2] per GPU: `n_jobs` page jobs drawn by cycling the batch's
 	pages from a PINNED HOST ring -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + the page's contour rings (K3) ->
 	D2H of the dewarped page and the warped contours, on three streams (upload / kernels / download) with
 	`slots` device slots.  The last job's page is checked against the resident path's output.  Returns
-	(elapsed seconds of this rank, bytes up, bytes down)."""
+	(elapsed seconds of this rank, bytes up, bytes down).
+	streams = (upload, kernels, download): the process must not hold more streams than the GPU_MAX_HW_QUEUES = 4
+	hardware queues it gets — with a fifth stream two of them share a queue, upload and download take turns and
+	the leg runs at a third of the PCIe rate (measured: 4.2 instead of 1.6 ms/page)."""
 	W, H = PAGE
 	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
 	n_pages = wl["pages"].shape[0]
@@ -268,7 +271,7 @@ def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, slots=3):
 	host_pts = torch.empty((slots + 1, max_pts, 2), dtype=torch.float64, pin_memory=True)
 	d_in = torch.empty((slots, H, W), dtype=torch.uint8, device=dev)
 	d_out = torch.empty((slots, Hd, Wd), dtype=torch.uint8, device=dev)
-	s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+	s_in, s_k, s_out = streams
 	ev_in = [torch.cuda.Event() for _ in range(slots)]
 	ev_k = [torch.cuda.Event() for _ in range(slots)]
 	ev_out = [torch.cuda.Event() for _ in range(slots)]
@@ -435,7 +438,9 @@ def main():
 				dist.barrier()
 				torch.cuda.synchronize()
 		n_jobs = args.pipeline_jobs or 2 * args.pages
-		p_elapsed, up, down = pipeline_leg(torch, lib, check, wl, n_jobs, barrier)
+		# kernels on the stream the timed steps used, uploads on their side stream, downloads on a third
+		p_elapsed, up, down = pipeline_leg(
+			torch, lib, check, wl, n_jobs, barrier, (side, torch.cuda.current_stream(), torch.cuda.Stream()))
 		t = torch.tensor([p_elapsed], dtype=torch.float64, device=dev)
 		if world > 1:
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)

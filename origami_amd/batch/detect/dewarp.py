@@ -16,7 +16,8 @@ import click
 
 from ... import _shim
 from ...dewarp import Grid, Samples
-from ...geometry import parse_wkt, to_wkt_many
+from ...geometry import parse_wkt, to_wkt, to_wkt_many
+from ...repair import RepairError
 from ..core.io import Artifact, Input, Output, Stage
 from ..core.processor import Processor
 
@@ -53,9 +54,12 @@ def dewarped_contours(warped, transformer, min_areas):
 		if geom.geom_type not in ("Polygon", "LineString"):
 			logging.error("dewarped contour %s is %s" % (name, geom.geom_type))
 		if not geom.valid_given(ring_flags):
-			# the reference repairs with shapely's buffer(0) (GEOS); this build has no polygon
-			# repair and passes the geometry on as it is
-			logging.error("invalid geom %s", name)
+			try:
+				geom = geom.buffer0()  # shapely's geom.buffer(0), ref: dewarp.py:36 (origami_amd/repair.py)
+			except RepairError as e:
+				logging.error("contour %s is invalid and could not be repaired (%s); written as it is." % (name, e))
+			if not geom.is_valid:
+				logging.error("invalid geom %s", to_wkt(geom))
 		kept_names.append(name)
 		kept.append(geom)
 	for name, text in zip(kept_names, to_wkt_many(kept)):

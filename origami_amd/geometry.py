@@ -17,15 +17,23 @@ _PLAIN = re.compile(r"^[-+0-9.eE,\s]*$")
 
 
 class Geom:
-	"""A Polygon (rings[0] = shell, rest = holes) or a LineString (one ring)."""
+	"""A Polygon (rings[0] = shell, rest = holes), a LineString (one ring) or — only as the result of a repair
+	(buffer0) or read back from a repaired contour — a MultiPolygon (parts = [[shell, hole, ...], ...];
+	`rings` then lists the rings of all parts in order)."""
 
-	__slots__ = ("geom_type", "rings")
+	__slots__ = ("geom_type", "rings", "parts")
 
 	def __init__(self, geom_type, rings):
-		if geom_type not in ("Polygon", "LineString"):
+		if geom_type not in ("Polygon", "LineString", "MultiPolygon"):
 			raise ValueError("unsupported geometry type %s" % geom_type)
 		self.geom_type = geom_type
-		self.rings = [np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]
+		as_ring = lambda r: np.asarray(r, dtype=np.float64).reshape(-1, 2)
+		if geom_type == "MultiPolygon":
+			self.parts = [[as_ring(r) for r in part] for part in rings]
+			self.rings = [r for part in self.parts for r in part]
+		else:
+			self.rings = [as_ring(r) for r in rings]
+			self.parts = [self.rings] if geom_type == "Polygon" and self.rings else []
 
 	@property
 	def is_empty(self):
@@ -33,12 +41,29 @@ class Geom:
 
 	@property
 	def area(self):
-		if self.geom_type != "Polygon" or self.is_empty:
+		if self.geom_type == "LineString" or self.is_empty:
 			return 0.0
-		a = abs(ring_area_signed(self.rings[0]))
-		for hole in self.rings[1:]:
-			a -= abs(ring_area_signed(hole))
+		a = 0.0
+		for part in self.parts:
+			a += abs(ring_area_signed(part[0]))
+			for hole in part[1:]:
+				a -= abs(ring_area_signed(hole))
 		return a
+
+	def buffer0(self):
+		"""`geom.buffer(0)` as the dewarp stage uses it to repair an invalid contour (ref: origami/batch/detect/
+		dewarp.py:36): the area GEOS keeps (origami_amd/repair.py) as a Polygon, a MultiPolygon, or POLYGON EMPTY
+		(always for a LineString: a line has no area)."""
+		from .repair import buffer0_rings
+		polygons = []
+		if self.geom_type != "LineString":
+			for part in self.parts:
+				polygons.extend(buffer0_rings(part))
+		if not polygons:
+			return Geom("Polygon", [])
+		if len(polygons) == 1:
+			return Geom("Polygon", polygons[0])
+		return Geom("MultiPolygon", polygons)
 
 	@property
 	def is_valid(self):
@@ -53,8 +78,14 @@ class Geom:
 		if self.geom_type == "LineString":
 			r = self.rings[0]
 			return len(r) >= 2 and bool(np.all(np.isfinite(r))) and not bool(np.all(r == r[0]))
-		flags = crossing if crossing is not None else [None] * len(self.rings)
-		return all(_ring_is_valid(r, c) for r, c in zip(self.rings, flags)) and _holes_inside(self.rings)
+		flags = list(crossing) if crossing is not None else [None] * len(self.rings)
+		k = 0
+		for part in self.parts:
+			n = len(part)
+			if not all(_ring_is_valid(r, c) for r, c in zip(part, flags[k:k + n])) or not _holes_inside(part):
+				return False
+			k += n
+		return True
 
 	def transform(self, fn):
 		"""shapely.ops.transform: fn(xs, ys) -> (xs', ys') applied ring by ring."""
@@ -62,10 +93,17 @@ class Geom:
 		for r in self.rings:
 			x, y = fn(tuple(r[:, 0]), tuple(r[:, 1]))
 			out.append(np.stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)], axis=1))
-		return Geom(self.geom_type, out)
+		return self.with_rings(out)
 
 	def with_rings(self, rings):
-		return Geom(self.geom_type, rings)
+		"""The same geometry with every ring replaced (rings in the order of `self.rings`)."""
+		if self.geom_type != "MultiPolygon":
+			return Geom(self.geom_type, rings)
+		parts, k = [], 0
+		for part in self.parts:
+			parts.append(rings[k:k + len(part)])
+			k += len(part)
+		return Geom("MultiPolygon", parts)
 
 	@property
 	def wkt(self):
@@ -141,17 +179,34 @@ def _holes_inside(rings):
 def parse_wkt(text):
 	"""POLYGON / LINESTRING (2-D) -> Geom."""
 	text = text.strip()
-	m = re.match(r"^(POLYGON|LINESTRING)\s*(Z\s*)?(EMPTY|\(.*\))\s*$", text, re.IGNORECASE | re.DOTALL)
+	m = re.match(r"^(MULTIPOLYGON|POLYGON|LINESTRING)\s*(Z\s*)?(EMPTY|\(.*\))\s*$", text, re.IGNORECASE | re.DOTALL)
 	if not m:
 		raise ValueError("unsupported WKT: %.40s" % text)
-	kind = "Polygon" if m.group(1).upper() == "POLYGON" else "LineString"
+	kind = {"POLYGON": "Polygon", "LINESTRING": "LineString", "MULTIPOLYGON": "MultiPolygon"}[m.group(1).upper()]
 	body = m.group(3)
 	if body.upper() == "EMPTY":
 		return Geom(kind, [])
+	if kind == "MultiPolygon":
+		# "((ring), (ring)), ((ring))": a polygon is a parenthesis group at depth 1 of the body
+		polygons, depth, start = [], 0, 0
+		for i, ch in enumerate(body[1:-1]):
+			if ch == "(":
+				if depth == 0:
+					start = i
+				depth += 1
+			elif ch == ")":
+				depth -= 1
+				if depth == 0:
+					polygons.append(_parse_rings(_RING.findall(body[1:-1][start + 1:i])))
+		return Geom(kind, polygons)
 	if kind == "LineString":
 		parts = [body[1:-1]]
 	else:
 		parts = _RING.findall(body[1:-1])
+	return Geom(kind, _parse_rings(parts))
+
+
+def _parse_rings(parts):
 	rings = []
 	for part in parts:
 		n_coord = part.count(",") + 1 if part.strip() else 0
@@ -166,7 +221,7 @@ def parse_wkt(text):
 		if dim < 2 or dim * n_coord != len(nums):
 			raise ValueError("malformed WKT coordinates")
 		rings.append(nums.reshape(n_coord, dim)[:, :2])
-	return Geom(kind, rings)
+	return rings
 
 
 def format_number(v):
@@ -183,6 +238,11 @@ def _ring_text(r):
 
 
 def to_wkt(geom):
+	if geom.geom_type == "MultiPolygon":
+		if geom.is_empty:
+			return "MULTIPOLYGON EMPTY"
+		return "MULTIPOLYGON (" + ", ".join(
+			"(" + ", ".join(_ring_text(r) for r in part) + ")" for part in geom.parts) + ")"
 	if geom.geom_type == "Polygon":
 		if geom.is_empty:
 			return "POLYGON EMPTY"
@@ -201,6 +261,9 @@ def to_wkt_many(geoms):
 	for g in geoms:
 		if g.is_empty:
 			out.append(to_wkt(g))
+		elif g.geom_type == "MultiPolygon":
+			out.append("MULTIPOLYGON (" + ", ".join(
+				"(" + ", ".join(next(texts) for _ in part) + ")" for part in g.parts) + ")")
 		elif g.geom_type == "Polygon":
 			out.append("POLYGON (" + ", ".join(next(texts) for _ in g.rings) + ")")
 		else:

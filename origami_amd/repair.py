@@ -311,6 +311,23 @@ def buffer0_rings(rings):
 			f = region[f]
 		return f
 
+	# The walk gives every connected component an outer face of its own; in the plane that face IS the face of
+	# another component the component lies in (a hole ring floating inside its shell), or the unbounded one.
+	if n_comp > 1:
+		loops_xy = [[coords[h[0]] for h in loop] + [coords[loop[0][0]]] for loop in faces]
+		for c, f0 in outer.items():
+			p = coords[faces[f0][0][0]]
+			best = None
+			for f, loop in enumerate(faces):
+				if comp[loop[0][0]] == c or f == outer[comp[loop[0][0]]]:
+					continue
+				if (best is None or area[f] < area[best]) and _winding(loops_xy[f], p) != 0:
+					best = f
+			if best is not None:
+				if depth[best] != depth[f0]:
+					raise RepairError("nested components disagree on the depth of their common face")
+				region[find(f0)] = find(best)
+
 	boundary = set()
 	for (u, v) in delta:
 		for h in ((u, v), (v, u)):

@@ -128,6 +128,51 @@ def test_dewarp_stage_config0_full_size(gpu, tmp_path):
 	np.testing.assert_array_equal(np.array(page.dewarped), want)
 
 
+def test_invalid_warped_contours_are_repaired_like_buffer0(gpu, tmp_path, caplog):
+	"""ref: origami/batch/detect/dewarp.py:35-38 — a contour that is invalid after the warp is replaced by its
+	buffer(0).  A bow-tie whose edges cross (one lobe survives), the shapely manual's self-touching bow-tie (both
+	lobes: MULTIPOLYGON) and a degenerate separator (POLYGON EMPTY, as shapely writes for a line's buffer) go
+	through the stage; the written geometry must contain exactly the points GEOS' depth rule keeps of the
+	oracle-warped ring (oracle/rings.py:buffer0_depth)."""
+	from oracle import rings as orings
+	rng = np.random.default_rng(41)
+	size = (600, 800)
+	page_path = synth.write_page_dir(
+		tmp_path, "page0001", rng, size=size, n_h=120, n_v=160, n_regions=4, n_separators=1,
+		label_size=(320, 427), warp=synth.Warp(size, 0.03, 0.025, 1, 2))
+	out = page_path.with_suffix(".out")
+	cross = np.array([[100, 100], [300, 300], [300, 100], [100, 300], [100, 100]], dtype=np.float64)
+	touch = np.array([[350, 400], [350, 600], [450, 500], [550, 600], [550, 400], [450, 500], [350, 400]], dtype=np.float64)
+	with zipfile.ZipFile(out / "contours.0.zip", "a") as zf:
+		zf.writestr("regions/TEXT/900.wkt", geometry.to_wkt(geometry.Geom("Polygon", [cross])))
+		zf.writestr("regions/TEXT/901.wkt", geometry.to_wkt(geometry.Geom("Polygon", [touch])))
+		zf.writestr("separators/V/900.wkt", "LINESTRING (200 200, 200 200)")
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	with zipfile.ZipFile(out / "dewarp.zip") as zf:
+		data = np.load(io.BytesIO(zf.read("data.npy")))
+	tf = odw.Grid(data, 25).transformer
+	with zipfile.ZipFile(out / "contours.1.zip") as zf:
+		got_cross = geometry.parse_wkt(zf.read("regions/TEXT/900.wkt").decode("utf8"))
+		got_touch = geometry.parse_wkt(zf.read("regions/TEXT/901.wkt").decode("utf8"))
+		assert zf.read("separators/V/900.wkt") == b"POLYGON EMPTY"
+		valid = geometry.parse_wkt(zf.read("regions/TEXT/0.wkt").decode("utf8"))
+	assert valid.geom_type == "Polygon" and len(valid.rings) == 1  # valid contours pass through untouched
+	assert got_cross.geom_type == "Polygon" and len(got_cross.parts) == 1 and got_cross.is_valid
+	assert got_touch.geom_type == "MultiPolygon" and len(got_touch.parts) == 2 and got_touch.is_valid
+	for src, got in ((cross, got_cross), (touch, got_touch)):
+		warped = odw.transform_rings(tf, [src])[0]
+		lo, hi = warped.min(axis=0) - 5, warped.max(axis=0) + 5
+		pts = rng.uniform(lo, hi, size=(400, 2))
+		# off the outline by more than the 1e-3 px the two transformers may differ
+		for p in pts:
+			want = orings.buffer0_depth([warped], p) >= 1
+			near = min(np.hypot(*(warped[:-1] + t * (warped[1:] - warped[:-1]) - p).T).min() for t in np.linspace(0, 1, 201))
+			if near > 0.5:
+				assert orings.point_in_polygons(got.parts, p) == want
+		assert abs(got.area - sum(abs(0.5 * np.sum(r[:-1, 0] * r[1:, 1] - r[1:, 0] * r[:-1, 1])) for part in got.parts for r in part)) < 1e-6
+
+
 def test_page_without_regions_is_skipped_silently(gpu, tmp_path):
 	rng = np.random.default_rng(12)
 	page_path = synth.write_page_dir(tmp_path, "empty", rng, size=(300, 400), n_h=20, n_v=20, n_regions=0, n_separators=1, label_size=(160, 213))

@@ -152,7 +152,16 @@ def test_validity_and_transform():
 	assert moved.wkt == "POLYGON ((1 0, 5 0, 5 8, 1 8, 1 0))"
 	assert moved.area == 32
 	with pytest.raises(ValueError):
-		geometry.parse_wkt("MULTIPOLYGON (((0 0, 1 0, 1 1, 0 0)))")
+		geometry.parse_wkt("MULTILINESTRING ((0 0, 1 0))")
+	# a repaired contour may come back from contours.1.zip as a MultiPolygon (ref: batch/detect/dewarp.py:36-39)
+	multi = geometry.parse_wkt(
+		"MULTIPOLYGON (((0 0, 0 4, 4 4, 4 0, 0 0), (1 1, 2 1, 2 2, 1 1)), ((10 10, 10 12, 12 12, 10 10)))")
+	assert [len(p) for p in multi.parts] == [2, 1] and len(multi.rings) == 3
+	assert multi.area == 16 - 0.5 + 2 and multi.is_valid
+	assert multi.wkt == "MULTIPOLYGON (((0 0, 0 4, 4 4, 4 0, 0 0), (1 1, 2 1, 2 2, 1 1)), ((10 10, 10 12, 12 12, 10 10)))"
+	assert geometry.to_wkt_many([multi, square]) == [multi.wkt, square.wkt]
+	moved = multi.transform(lambda x, y: (np.asarray(x) + 1, np.asarray(y)))
+	assert [len(p) for p in moved.parts] == [2, 1] and moved.rings[2][0].tolist() == [11, 10]
 
 
 def test_synthetic_page_dir_layout(tmp_path):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput (ii) of SURVEY §8d: pinned host -> H2D -> fused dewarp (K1a∘K2) -> D2H, overlapped on three
 streams with a ring of device slots.  PCIe-inclusive; never bench.py's `value`.
-usage: pipeline_bench.py [n_pages slots]"""
+usage: pipeline_bench.py [n_pages slots ring]"""
 import sys
 import time
 from pathlib import Path
@@ -27,7 +27,7 @@ h, w = nodes.shape[:2]
 Hd, Wd = h * CELL, w * CELL
 nodes_d = torch.from_numpy(nodes).to(dev)
 
-ring = 8  # distinct pinned host pages cycled over the jobs
+ring = int(sys.argv[3]) if len(sys.argv) > 3 else 8  # distinct pinned host pages cycled over the jobs
 base = synth.text_page(rng, (W, H))
 host_in = torch.empty((ring, H, W), dtype=torch.uint8).pin_memory()
 for k in range(ring):
@@ -67,6 +67,7 @@ t0 = time.perf_counter()
 run(n_pages)
 dt = time.perf_counter() - t0
 mp = n_pages * Hd * Wd / 1e6
+print("ring %d:" % ring, end=" ")
 print("pipeline (pinned host in/out, %d slots, fused dewarp): %d pages in %.1f ms = %.2f ms/page = %.0f MP/s; "
 	"PCIe %.1f GB/s in + %.1f GB/s out" % (
 		slots, n_pages, dt * 1e3, dt / n_pages * 1e3, mp / dt, n_pages * H * W / dt / 1e9, n_pages * Hd * Wd / dt / 1e9))
