@@ -107,12 +107,13 @@ def test_march_rays_that_miss_the_next_row_retry_on_later_rows(gpu, monkeypatch,
 	# side float32 rounding put the start point (observed: the oracle stays put for four rows where the device,
 	# whose start point differs in the last bit, moves on at once; the reference's GEOS predicate flips the same
 	# coin).  Such columns show as vertically repeated nodes; they — and the border columns marched from them —
-	# are left out of the comparison, every other column must agree to 1e-3 px.
+	# are the only ones allowed to differ (and at most 15 % of all columns may); every other column must agree to 1e-3 px.
 	stuck = np.zeros(hv.shape[1], dtype=bool)
 	for g in (hv, want.hv):
 		stuck |= np.any(np.all(g[1:] == g[:-1], axis=-1), axis=0)
-	assert stuck.mean() <= 0.15, "too many degenerate columns to call this a comparison"
-	assert np.abs(hv - want.hv)[:, ~stuck].max() < 1e-3
+	differs = np.abs(hv - want.hv).max(axis=(0, 2)) >= 1e-3
+	assert not np.any(differs & ~stuck), "a column without a zero-distance hit differs"
+	assert differs.mean() <= 0.15, "too many degenerate columns differ to call this a comparison"
 
 
 def test_constant_fields_give_a_regular_grid(gpu):
