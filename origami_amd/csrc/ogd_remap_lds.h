@@ -93,8 +93,10 @@ struct MapGlobal {
   }
 
   template <int LX, int RPT>
-  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int) const {
+  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int, float, float,
+                                       bool& interior) const {
     constexpr int RW = 64 / LX;
+    interior = false;  // nothing is known about a map read from memory: always clamp
     if (X + 4 <= Wd) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
@@ -145,47 +147,68 @@ struct MapNodesT {
   // caller then takes the per-pixel path for the tile.
   template <int LX, int RPT>
   __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t* lds, int lds_dwords,
-                                       int lane, int X0, int Y0) const {
+                                       int lane, int X0, int Y0, float xmax, float ymax, bool& interior) const {
     constexpr int RW = 64 / LX, TW = 4 * LX, TH = RW * RPT;
-    static_assert(TW <= 64 && TH <= 64, "one tile column / row per lane");
-    // lane l: x tap of tile column l, y tap of tile row l (clamped to the tile; the taps are monotone)
-    const Tap txl = tap_x(min(X0 + min(lane, TW - 1), Wd - 1), inv_s, w);
-    const Tap tyl = tap_y(min(Y0 + min(lane, TH - 1), Hd - 1), inv_s, h);
-    const int jlo = __builtin_amdgcn_readfirstlane(txl.i0), jhi = __builtin_amdgcn_readlane(txl.i1, TW - 1);
-    const int ilo = __builtin_amdgcn_readfirstlane(tyl.i0), ihi = __builtin_amdgcn_readlane(tyl.i1, TH - 1);
-    const int nc = jhi - jlo + 1, nr = ihi - ilo + 1, nn = nc * nr;
-    // LDS (dwords): nodes float2[nn] | rows float2[nr][TW] (16-byte aligned) | y taps float4[TH]
-    const int o_rows = (2 * nn + 3) & ~3, o_yt = o_rows + 2 * nr * TW;
-    if (o_yt + 4 * TH > lds_dwords) return false;  // wave-uniform
+    static_assert(TW <= 32 && TH <= 32, "one tile column per lane of the lower half-wave, one tile row per lane of the upper");
+    constexpr int NP = 8;  // node sub-grid pitch: one node per lane (8 x 8)
+    // Lower half-wave: x tap of tile column l5; upper half-wave: y tap of tile row l5 (clamped to the tile; the
+    // taps are monotone).  One evaluation of the fp64 chain per lane serves both axes (ogd_resize_math.h:
+    // tap_x / tap_y differ only in how the ends are clamped).
+    const int half = lane >> 5, l5 = lane & 31;
+    const int n = half ? h : w;
+    const int pos = half ? min(Y0 + min(l5, TH - 1), Hd - 1) : min(X0 + min(l5, TW - 1), Wd - 1);
+    float f = (float)(((double)pos + 0.5) * inv_s - 0.5);
+    const float fl = floorf(f);
+    const int i = (int)fl;
+    f = f - fl;
+    const int i0 = min(max(i, 0), n - 1);
+    // x: a tap clamped at either end loses its fraction and keeps its right neighbour min(i0 + 1, n - 1);
+    // y: both rows are clamped, the fraction stays
+    const bool xclamp = !half && (i < 0 || i >= n - 1);
+    const int i1 = (!half && i < 0) ? min(1, n - 1) : min(max(i + 1, 0), n - 1);
+    if (xclamp) f = 0.f;
+    const float w0 = 1.f - f, w1 = f;
+    const int jlo = __builtin_amdgcn_readfirstlane(i0), jhi = __builtin_amdgcn_readlane(i1, TW - 1);
+    const int ilo = __builtin_amdgcn_readlane(i0, 32), ihi = __builtin_amdgcn_readlane(i1, 32 + TH - 1);
+    const int nc = jhi - jlo + 1, nr = ihi - ilo + 1;
+    // LDS (dwords): nodes float2[8][8] | rows float2[nr][TW] | y taps float4[TH]
+    constexpr int o_rows = 2 * NP * NP;
+    const int o_yt = o_rows + 2 * nr * TW;
+    if (nc > NP || nr > NP || o_yt + 4 * TH > lds_dwords) return false;  // wave-uniform (cells of a few pixels)
     {
       float2* ln = reinterpret_cast<float2*>(lds);
       float2* rows = reinterpret_cast<float2*>(lds + o_rows);
       float4* ytab = reinterpret_cast<float4*>(lds + o_yt);
-      for (int idx = lane; idx < nn; idx += 64) {
-        const int r = idx / nc, c = idx - r * nc;
-        ln[idx] = ((rl_gf2)nodes)[(size_t)(ilo + r) * w + jlo + c];
+      const int r = lane >> 3, c = lane & (NP - 1);
+      bool ok = true;
+      if (r < nr && c < nc) {
+        const float2 v = ((rl_gf2)nodes)[(size_t)(ilo + r) * w + jlo + c];
+        ln[lane] = v;
+        // Every map value of the tile is a convex combination of these nodes (up to rounding): if all of them
+        // lie a pixel inside the clamp range, the clamp of step 1 is the identity for the whole tile.
+        const float vx = UNIT ? v.x : __fmul_rn(v.x, scx), vy = UNIT ? v.y : __fmul_rn(v.y, scy);
+        ok = vx >= -1.f && vx <= xmax && vy >= -1.f && vy <= ymax;  // false for NaN
       }
-      if (lane < TH)
-        ytab[lane] = make_float4(__int_as_float((tyl.i0 - ilo) * TW), __int_as_float((tyl.i1 - ilo) * TW), tyl.w0, tyl.w1);
+      interior = __builtin_amdgcn_ballot_w64(!ok) == 0;
+      if (half && l5 < TH)
+        ytab[l5] = make_float4(__int_as_float((i0 - ilo) * TW), __int_as_float((i1 - ilo) * TW), w0, w1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (lane < TW) {
-        const int c0 = txl.i0 - jlo, c1 = txl.i1 - jlo;
-        for (int r = 0; r < nr; ++r) {  // wave-uniform trip count (2..3 for a 25-px cell)
-          const float2 a = ln[r * nc + c0], b = ln[r * nc + c1];
-          rows[r * TW + lane] = make_float2(lerp2(a.x, txl.w0, b.x, txl.w1), lerp2(a.y, txl.w0, b.y, txl.w1));
+        const int c0 = i0 - jlo, c1 = i1 - jlo;
+        for (int rr = 0; rr < nr; ++rr) {  // wave-uniform trip count (2..3 for a 25-px cell)
+          const float2 a = ln[rr * NP + c0], b = ln[rr * NP + c1];
+          rows[rr * TW + lane] = make_float2(lerp2(a.x, w0, b.x, w1), lerp2(a.y, w0, b.y, w1));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int lx4 = (lane % LX) * 4, ly = lane / LX;
-      // (v_pk_mul_f32 / v_pk_add_f32 for the (x, y) pairs were measured: fewer instructions, 4 % slower —
-      // packed fp32 issues at half rate here)
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const float4 yt = ytab[ly + r * RW];
+      for (int r2 = 0; r2 < RPT; ++r2) {
+        const float4 yt = ytab[ly + r2 * RW];
         const float4* t0 = reinterpret_cast<const float4*>(rows + __float_as_int(yt.x) + lx4);
         const float4* t1 = reinterpret_cast<const float4*>(rows + __float_as_int(yt.y) + lx4);
 #pragma unroll
@@ -199,10 +222,10 @@ struct MapNodesT {
             bx = __fmul_rn(bx, scx);
             by = __fmul_rn(by, scy);
           }
-          mv[r][4 * k2 + 0] = ax;
-          mv[r][4 * k2 + 1] = ay;
-          mv[r][4 * k2 + 2] = bx;
-          mv[r][4 * k2 + 3] = by;
+          mv[r2][4 * k2 + 0] = ax;
+          mv[r2][4 * k2 + 1] = ay;
+          mv[r2][4 * k2 + 2] = bx;
+          mv[r2][4 * k2 + 3] = by;
         }
       }
     }
@@ -270,7 +293,9 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
   const int X = bx * TW + lx4;
   const int Yb = by * TH + ly;  // row of pass r: Yb + r * RW
   float mv[RPT][8];
-  if (!ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH)) {  // wave-uniform
+  bool interior;  // wave-uniform: the clamp below cannot change any map value of this tile
+  if (!ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH, (float)(W - 1), (float)(H - 1),
+                                 interior)) {  // wave-uniform
     remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb);
     return;
   }
@@ -286,12 +311,20 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
   int lp[RPT][4];
   uint32_t wa[RPT][4], wb[RPT][4];
   int mn = 0x7fff7fff, mx = (int)0x80008000;
+  if (!interior) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        mv[r][k] = __builtin_amdgcn_fmed3f(mv[r][k], xlo, xhi);
+        mv[r][k + 1] = __builtin_amdgcn_fmed3f(mv[r][k + 1], ylo, yhi);
+      }
+  }
 #pragma unroll
   for (int r = 0; r < RPT; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float cxf = __builtin_amdgcn_fmed3f(mv[r][2 * k], xlo, xhi);
-      const float cyf = __builtin_amdgcn_fmed3f(mv[r][2 * k + 1], ylo, yhi);
+      const float cxf = mv[r][2 * k], cyf = mv[r][2 * k + 1];
       const uint32_t qbx = __float_as_uint(LIN ? __builtin_fmaf(cxf, 32.f, MAGIC) : __fadd_rn(cxf, MAGIC));
       const uint32_t qby = __float_as_uint(LIN ? __builtin_fmaf(cyf, 32.f, MAGIC) : __fadd_rn(cyf, MAGIC));
       const int cx = __builtin_amdgcn_sbfe((int)qbx, SHIFT, 16), cy = __builtin_amdgcn_sbfe((int)qby, SHIFT, 16);
