@@ -1,12 +1,15 @@
-"""Artifacts of a page and their readers / writers — the part of origami/batch/core/io.py the dewarp
-and line-export stages touch (same names, file names and skip / overwrite rules).
+"""Page artifacts on disk: which files a stage reads and writes, under which names, and when a page counts as
+ready, done or half-done.
 
-ref: origami/batch/core/io.py:25-62 (find_data_path, Stage, Artifact), :92-103 (DebuggingArtifact, Annotation),
-:109-146 (read_contours), :166-224 (Regions, Lines), :227-373 (Reader), :375-387 (Input),
-:411-416 (AtomicFileWriter), :507-620 (Writer, Output).
+This is the slice of the reference's artifact layer that the dewarp and line-export stages touch
+(ref: origami/batch/core/io.py — names and rules: :25-62 stages and file names, :92-103 annotations, :109-146 the
+contour zip, :192-224 the line zip, :231-236 implied inputs, :261-265 / :542-543 readiness, :533-540 half-written
+output sets, :411-416 atomic writes, :565-577 meta members copied first, :606-610 annotation images).  What a
+drop-in must share with the reference is the schema — enum members, file names, member order, error messages —
+and that is all this module shares; the code is organised around one table of file-name patterns and one common
+base for the reading and the writing side.
 """
 
-import collections
 import enum
 import json
 import os
@@ -14,11 +17,13 @@ import tempfile
 import zipfile
 from contextlib import contextmanager
 from pathlib import Path
+from typing import NamedTuple
 
 from ...geometry import parse_wkt
 
 
 def find_data_path(page_path):
+	"""`<page>.out/`, the directory of a page's artifacts."""
 	return Path(page_path).with_suffix(".out")
 
 
@@ -31,49 +36,51 @@ class Stage(enum.Enum):
 
 	@property
 	def is_dewarped(self):
-		return self.value >= Stage.DEWARPED.value
+		return self.value > Stage.WARPED.value
+
+
+# file-name pattern of every artifact; a "%s" is filled with the number of the stage the file belongs to
+_PATTERNS = dict(
+	SEGMENTATION="segment.zip", FLOW="flow.zip", DEWARPING_TRANSFORM="dewarp.zip", TABLES="tables.json",
+	RUNTIME="runtime.json", CONTOURS="contours.%s.zip", LINES="lines.%s.zip")
+# stages at which a staged artifact exists
+_STAGED = dict(
+	CONTOURS=(Stage.WARPED, Stage.DEWARPED, Stage.AGGREGATE, Stage.RELIABLE),
+	LINES=(Stage.WARPED, Stage.RELIABLE))
 
 
 class Artifact(enum.Enum):
-	SEGMENTATION = ("segment.zip",)
-	FLOW = ("flow.zip",)
-	DEWARPING_TRANSFORM = ("dewarp.zip",)
-	TABLES = ("tables.json",)
-	RUNTIME = ("runtime.json",)
-	CONTOURS = ("contours.%s.zip", {
-		Stage.WARPED: 0,
-		Stage.DEWARPED: 1,
-		Stage.AGGREGATE: 2,
-		Stage.RELIABLE: 3})
-	LINES = ("lines.%s.zip", {
-		Stage.WARPED: 0,
-		Stage.RELIABLE: 3})
-
-	def __init__(self, filename, stages=None):
-		self._filename = filename
-		self._stages = stages
+	SEGMENTATION = enum.auto()
+	FLOW = enum.auto()
+	DEWARPING_TRANSFORM = enum.auto()
+	TABLES = enum.auto()
+	RUNTIME = enum.auto()
+	CONTOURS = enum.auto()
+	LINES = enum.auto()
 
 	def filename(self, stage=None):
-		s = self._filename
-		if self._stages is not None:
-			if stage is None:
-				raise RuntimeError("need to specify stage for loading %s" % self)
-			variant = self._stages.get(stage)
-			if variant is None:
-				raise RuntimeError("%s is not supported for stage %s" % (self, stage))
-			s = s % str(variant)
-		return s
+		pattern = _PATTERNS[self.name]
+		stages = _STAGED.get(self.name)
+		if stages is None:
+			return pattern
+		if stage is None:
+			raise RuntimeError("need to specify stage for loading %s" % self)
+		if stage not in stages:
+			raise RuntimeError("%s is not supported for stage %s" % (self, stage))
+		return pattern % stage.value
 
 
-class DebuggingArtifact:  # ref: io.py:92-97
+class DebuggingArtifact:
+	"""A file that is a by-product, not an input of any stage."""
+
 	def __init__(self, filename):
-		self._filename = filename
+		self._name = filename
 
 	def filename(self, stage=None):
-		return self._filename
+		return self._name
 
 
-class Annotation(DebuggingArtifact):  # ref: io.py:100-103
+class Annotation(DebuggingArtifact):
 	def __init__(self, name):
 		super().__init__("annotation.%s.jpg" % name)
 
@@ -83,45 +90,44 @@ class PredictorType(enum.Enum):  # ref: origami/core/predict.py:136-138
 	SEPARATOR = 2
 
 
-Contours = collections.namedtuple("Contours", ["items", "meta"])
+# ---- zip members ---------------------------------------------------------------------------------------
+
+def _member_path(name):
+	"""'regions/TEXT/3.wkt' -> ('regions', 'TEXT', '3')"""
+	return tuple(name.rpartition(".")[0].split("/"))
+
+
+class Contours(NamedTuple):
+	items: list  # [(member path, Geom)]
+	meta: dict  # {(predictor, label): contents of that folder's meta.json}
 
 
 def read_contours(path, pred_type, open=open):
-	"""[(path parts, Geom)] of one predictor type from a contours zip; ref: io.py:109-146."""
-	items = []
-	pred_meta = dict()
-	with open(path, "rb") as f:
-		with zipfile.ZipFile(f, "r") as zf:
-			meta = json.loads(zf.read("meta.json"))
-			if meta["version"] > 1:
-				predictions = dict((x["name"], x) for x in meta["predictions"])
-			else:
-				predictions = meta
-
-			def wanted(parts):
-				return PredictorType[predictions[parts[0]]["type"]] == pred_type
-
-			for name in zf.namelist():
-				if name.endswith("/meta.json"):
-					parts = tuple(name.split("/"))
-					if wanted(parts):
-						pred_meta[tuple(parts[:-1])] = json.loads(zf.read(name))
-				if not name.endswith(".wkt"):
-					continue
-				parts = tuple(name.rsplit(".", 1)[0].split("/"))
-				if wanted(parts):
-					items.append((parts, parse_wkt(zf.read(name).decode("utf8"))))
-	return Contours(items, pred_meta)
+	"""The geometries of one predictor type (regions or separators) in a contours zip, in member order, with the
+	per-label meta.json files of the same predictors."""
+	with open(path, "rb") as f, zipfile.ZipFile(f, "r") as zf:
+		head = json.loads(zf.read("meta.json"))
+		# version 1 keyed the predictors by name at the top level, version 2 lists them
+		kinds = head if head["version"] <= 1 else {p["name"]: p for p in head["predictions"]}
+		of_type = {name for name, p in kinds.items() if isinstance(p, dict) and PredictorType[p["type"]] == pred_type}
+		geoms, meta = [], {}
+		for name in zf.namelist():
+			if name.partition("/")[0] not in of_type:
+				continue
+			if name.endswith("/meta.json"):
+				meta[tuple(name.split("/")[:-1])] = json.loads(zf.read(name))
+			elif name.endswith(".wkt"):
+				geoms.append((_member_path(name), parse_wkt(zf.read(name).decode("utf8"))))
+	return Contours(geoms, meta)
 
 
 class Regions:
-	"""ref: io.py:166-189.  `page` may be a zero-argument callable (see Block)."""
+	"""Blocks of a page by member path.  `page` may be a zero-argument callable (see Block)."""
 
 	def __init__(self, path, page, stage, open=open):
 		from ...block import Block
-		self._blocks = dict(
-			(parts, Block(page, polygon, stage))
-			for parts, polygon in read_contours(path, PredictorType.REGION, open=open).items)
+		found = read_contours(path, PredictorType.REGION, open=open)
+		self._blocks = {where: Block(page, polygon, stage) for where, polygon in found.items}
 
 	@property
 	def by_path(self):
@@ -129,26 +135,24 @@ class Regions:
 
 
 class Lines:
-	"""ref: io.py:192-224 — one JSON per line (Line.info) under the path of its block."""
+	"""The lines zip: `meta.json` plus one JSON per line (Line.info) filed under its block's path."""
 
 	def __init__(self, path, regions, stage=Stage.WARPED, open=open):
 		from ...block import Line
 		blocks = regions.by_path
-		assert all(block.stage == stage for block in blocks.values())
-		self._meta = None
-		lines = dict()
-		with open(path, "rb") as lf:
-			with zipfile.ZipFile(lf, "r") as zf:
-				for name in zf.namelist():
-					if name == "meta.json":
-						self._meta = json.loads(zf.read(name))
-						continue
-					if not name.endswith(".json"):
-						raise RuntimeError("illegal file %s in %s." % (name, path))
-					parts = tuple(name.rsplit(".", 1)[0].split("/"))
-					block = blocks[tuple(parts[:3])]
-					lines[parts] = Line(block, **json.loads(zf.read(name)))
-		self._lines = lines
+		if any(b.stage != stage for b in blocks.values()):
+			raise AssertionError("blocks and lines of different stages")
+		self._meta, self._lines = None, {}
+		with open(path, "rb") as f, zipfile.ZipFile(f, "r") as zf:
+			for name in zf.namelist():
+				if not name.endswith(".json"):
+					raise RuntimeError("illegal file %s in %s." % (name, path))
+				record = json.loads(zf.read(name))
+				if name == "meta.json":
+					self._meta = record
+				else:
+					where = _member_path(name)
+					self._lines[where] = Line(blocks[where[:3]], **record)
 
 	@property
 	def meta(self):
@@ -163,41 +167,63 @@ class Lines:
 		return self._lines
 
 
-class Reader:
-	def __init__(self, artifacts, stage, page_path, take_any=False, open=open):
-		artifacts = set(artifacts)
-		if Artifact.LINES in artifacts:
-			artifacts.add(Artifact.CONTOURS)  # io.py:231-232
-		if Artifact.CONTOURS in artifacts:
-			artifacts.add(Artifact.SEGMENTATION)  # io.py:233-234
-		if stage and stage.is_dewarped and Artifact.CONTOURS in artifacts:
-			artifacts.add(Artifact.DEWARPING_TRANSFORM)
-		self._artifacts = artifacts
+# ---- the files of one page, as a stage declared them -----------------------------------------------------
+
+class _PageFiles:
+	"""Common to both sides: the declared artifacts of one page at one stage and where they live."""
+
+	_verb = "access"
+
+	def __init__(self, artifacts, stage, page_path):
+		self._artifacts = set(artifacts)
 		self._stage = stage
 		self._page_path = Path(page_path)
 		self._data_path = find_data_path(page_path)
-		self._take_any = take_any
-		self._open = open
-		self._cache = {}
 
 	@property
 	def data_path(self):
 		return self._data_path
 
+	def path(self, artifact):
+		if artifact not in self._artifacts:
+			raise RuntimeError("%s on undeclared %s" % (self._verb, artifact))
+		return self._data_path / artifact.filename(self._stage)
+
 	@property
 	def paths(self):
 		return [self.path(a) for a in self._artifacts]
 
-	def path(self, artifact):
-		if artifact not in self._artifacts:
-			raise RuntimeError("read on undeclared %s" % artifact)
-		return self._data_path / artifact.filename(self._stage)
+	def _present(self):
+		return [p.exists() for p in self.paths]
+
+
+class Reader(_PageFiles):
+	_verb = "read"
+
+	def __init__(self, artifacts, stage, page_path, take_any=False, open=open):
+		wanted = set(artifacts)
+		# lines hang off blocks, blocks off the segmentation's label names; dewarped contours need their grid
+		if Artifact.LINES in wanted:
+			wanted.add(Artifact.CONTOURS)
+		if Artifact.CONTOURS in wanted:
+			wanted.add(Artifact.SEGMENTATION)
+			if stage is not None and stage.is_dewarped:
+				wanted.add(Artifact.DEWARPING_TRANSFORM)
+		super().__init__(wanted, stage, page_path)
+		self._take_any = take_any
+		self._open = open
+		self._loaded = {}
+
+	def _once(self, key, load):
+		if key not in self._loaded:
+			self._loaded[key] = load()
+		return self._loaded[key]
 
 	def fix_inconsistent(self):
-		pass
+		pass  # inputs are never touched
 
 	def is_ready(self):
-		return True if self._take_any else all(p.exists() for p in self.paths)
+		return self._take_any or all(self._present())
 
 	@property
 	def missing(self):
@@ -205,42 +231,34 @@ class Reader:
 
 	@property
 	def page(self):
-		if "page" not in self._cache:
+		def load():
 			from ...page import Page
-			grid = self.dewarping_transform if self._stage.is_dewarped else None
-			self._cache["page"] = Page(self._page_path, grid)
-		return self._cache["page"]
+			return Page(self._page_path, self.dewarping_transform if self._stage.is_dewarped else None)
+		return self._once("page", load)
 
 	@property
 	def regions(self):
-		if "regions" not in self._cache:
-			self._cache["regions"] = Regions(
-				self.path(Artifact.CONTOURS), lambda: self.page, self._stage, open=self._open)
-		return self._cache["regions"]
+		return self._once("regions", lambda: Regions(
+			self.path(Artifact.CONTOURS), lambda: self.page, self._stage, open=self._open))
 
 	@property
 	def lines(self):
-		if "lines" not in self._cache:
-			self._cache["lines"] = Lines(
-				self.path(Artifact.LINES), self.regions, self._stage, open=self._open)
-		return self._cache["lines"]
+		return self._once("lines", lambda: Lines(
+			self.path(Artifact.LINES), self.regions, self._stage, open=self._open))
 
 	def load_json(self, artifact):
-		with open(self.path(artifact), "r") as f:
-			return json.loads(f.read())
+		return json.loads(self.path(artifact).read_text())
 
 	@property
 	def tables(self):
-		if "tables" not in self._cache:
-			self._cache["tables"] = self.load_json(Artifact.TABLES)
-		return self._cache["tables"]
+		return self._once("tables", lambda: self.load_json(Artifact.TABLES))
 
 	@property
 	def dewarping_transform(self):
-		if "grid" not in self._cache:
+		def load():
 			from ...dewarp import Grid
-			self._cache["grid"] = Grid.open(self.path(Artifact.DEWARPING_TRANSFORM))
-		return self._cache["grid"]
+			return Grid.open(self.path(Artifact.DEWARPING_TRANSFORM))
+		return self._once("grid", load)
 
 	@property
 	def flow(self):
@@ -248,20 +266,20 @@ class Reader:
 
 
 class Input:
+	"""Declaration of what a stage reads; the processor turns it into a Reader per page."""
+
 	def __init__(self, *artifacts, stage=None, take_any=False):
-		assert all(isinstance(x, Artifact) for x in artifacts)
-		self._artifacts = set(artifacts)
-		self._stage = stage
-		self._take_any = take_any
+		if not all(isinstance(a, Artifact) for a in artifacts):
+			raise AssertionError("inputs are Artifacts")
+		self._spec = dict(artifacts=set(artifacts), stage=stage, take_any=take_any)
 
 	def instantiate(self, processor, file_writer, **kwargs):
-		return Reader(
-			self._artifacts, self._stage, take_any=self._take_any, open=processor.lock_or_open, **kwargs)
+		return Reader(open=processor.lock_or_open, **self._spec, **kwargs)
 
 
 class AtomicFileWriter:
-	"""Write to a temporary file next to the target, then rename (atomicwrites' behaviour,
-	ref: io.py:411-416)."""
+	"""Files appear complete or not at all: written under a temporary name in the target's directory, renamed
+	on success (what the reference gets from `atomicwrites`)."""
 
 	def __init__(self, overwrite):
 		self._overwrite = overwrite
@@ -273,27 +291,28 @@ class AtomicFileWriter:
 	@contextmanager
 	def __call__(self, path, mode):
 		path = Path(path)
-		fd, tmp = tempfile.mkstemp(prefix=".tmp", dir=str(path.parent))
+		handle, scratch = tempfile.mkstemp(prefix=".tmp", dir=str(path.parent))
+		done = False
 		try:
-			with os.fdopen(fd, mode) as f:
+			with os.fdopen(handle, mode) as f:
 				yield f
-			if not self._overwrite and path.exists():
+			if path.exists() and not self._overwrite:
 				raise FileExistsError(str(path))
-			os.replace(tmp, path)
-		except BaseException:
-			try:
-				os.unlink(tmp)
-			except OSError:
-				pass
-			raise
+			os.replace(scratch, path)
+			done = True
+		finally:
+			if not done:
+				try:
+					os.unlink(scratch)
+				except OSError:
+					pass
 
 
-class Writer:
+class Writer(_PageFiles):
+	_verb = "write"
+
 	def __init__(self, artifacts, stage, page_path, processor, file_writer):
-		self._artifacts = artifacts
-		self._stage = stage
-		self._page_path = page_path
-		self._data_path = find_data_path(page_path)
+		super().__init__(artifacts, stage, page_path)
 		self._processor = processor
 		self._write = file_writer
 
@@ -301,31 +320,18 @@ class Writer:
 	def compression(self):
 		return zipfile.ZIP_DEFLATED
 
-	@property
-	def data_path(self):
-		return self._data_path
-
-	@property
-	def paths(self):
-		return [self.path(a) for a in self._artifacts]
-
-	def path(self, artifact):
-		if artifact not in self._artifacts:
-			raise RuntimeError("write on undeclared %s" % artifact)
-		return self._data_path / artifact.filename(self._stage)
-
 	def fix_inconsistent(self):
-		# a half-written output set is removed so that the page is redone (io.py:533-540)
+		"""Some but not all outputs exist (an interrupted run): remove them, so the page is done again."""
 		if self._write.overwrite:
 			return
-		e = [p.exists() for p in self.paths]
-		if any(e) and not all(e):
-			for p in self.paths:
-				if p.exists():
+		present = self._present()
+		if any(present) and not all(present):
+			for p, there in zip(self.paths, present):
+				if there:
 					os.remove(p)
 
 	def is_ready(self):
-		return self._write.overwrite or not any(p.exists() for p in self.paths)
+		return self._write.overwrite or not any(self._present())
 
 	@property
 	def missing(self):
@@ -333,21 +339,20 @@ class Writer:
 
 	@contextmanager
 	def write_zip_file(self, artifact):
-		with self._write(self.path(artifact), mode="wb") as f:
-			with zipfile.ZipFile(f, "w", self.compression) as zf:
-				yield zf
+		with self._write(self.path(artifact), mode="wb") as f, zipfile.ZipFile(f, "w", self.compression) as zf:
+			yield zf
 
 	@contextmanager
 	def contours(self, copy_meta_from=None):
-		with self.write_zip_file(Artifact.CONTOURS) as f:
+		"""The stage's contours zip, opened for writing; the meta members of `copy_meta_from`'s contours zip
+		(meta.json first, then every <predictor>/<label>/meta.json) are carried over before anything else."""
+		with self.write_zip_file(Artifact.CONTOURS) as out:
 			if copy_meta_from is not None:
-				path = copy_meta_from.path(Artifact.CONTOURS)
-				with zipfile.ZipFile(path, "r") as zf:
-					f.writestr("meta.json", zf.read("meta.json"))
-					for name in zf.namelist():
-						if name.endswith("/meta.json"):
-							f.writestr(name, zf.read(name))
-			yield f
+				with zipfile.ZipFile(copy_meta_from.path(Artifact.CONTOURS), "r") as src:
+					folders = [n for n in src.namelist() if n.endswith("/meta.json")]
+					for name in ["meta.json"] + folders:
+						out.writestr(name, src.read(name))
+			yield out
 
 	@contextmanager
 	def dewarping_transform(self):
@@ -355,22 +360,25 @@ class Writer:
 			yield f
 
 	def annotation(self, image):
-		"""ref: io.py:606-610 (image.save to annotation.<name>.jpg); written through the atomic writer here."""
-		assert len(self._artifacts) == 1
-		annotation = list(self._artifacts)[0]
-		assert isinstance(annotation, Annotation)
-		with self._write(self.path(annotation), mode="wb") as f:
+		"""annotation.<name>.jpg: a PIL image (saved as JPEG, as the reference does) or the bytes of an already
+		encoded file (Page.dewarped_jpeg: the device-side encoder)."""
+		(target,) = self._artifacts
+		if not isinstance(target, Annotation):
+			raise AssertionError("annotation() needs an Annotation output")
+		with self._write(self.path(target), mode="wb") as f:
 			if isinstance(image, (bytes, bytearray, memoryview)):
-				f.write(image)  # an already encoded file (Page.dewarped_jpeg: the device-side encoder)
+				f.write(image)
 			else:
 				image.save(f, format="JPEG")
 
 
 class Output:
+	"""Declaration of what a stage writes; the processor turns it into a Writer per page."""
+
 	def __init__(self, *artifacts, stage=None):
-		assert all(isinstance(x, (Artifact, DebuggingArtifact)) for x in artifacts)
-		self._artifacts = set(artifacts)
-		self._stage = stage
+		if not all(isinstance(a, (Artifact, DebuggingArtifact)) for a in artifacts):
+			raise AssertionError("outputs are Artifacts")
+		self._spec = dict(artifacts=set(artifacts), stage=stage)
 
 	def instantiate(self, **kwargs):
-		return Writer(self._artifacts, self._stage, **kwargs)
+		return Writer(**self._spec, **kwargs)

@@ -1,87 +1,108 @@
-"""Line images of a page for OCR / export (ref: origami/batch/core/lines.py:51-149).
+"""From the lines of a page to their images, for OCR and export.
 
-The reference maps `line.image(...)` over a ThreadPool(8), one small cv2.remap per line (lines.py:148);
-here all dewarped line images of a page come out of one launch (origami_amd.block.dewarped_line_images).
+Schema shared with the reference (origami/batch/core/lines.py:51-149): the classes `LineRewriter` and
+`LineExtractor`, the three CLI options, and the naming of table cells — a line `k` of a table block
+`<block>.<division>.*.*` that is cut at the block's column separators becomes the parts
+`<block>.<division>.<k + 1>.<column>` / `0`, columns counted from 1.  Everything else is this build's: the
+reference renders one line at a time on a thread pool (one small cv2.remap each, lines.py:148); here the whole
+page is planned first — which lines survive, which column intervals they are cut into — and all images of the
+plan come out of one launch (origami_amd.block.dewarped_line_images).
 """
 
-import functools
 import logging
+from typing import NamedTuple, Optional, Tuple
 
 import click
 
 from ...block import dewarped_line_images
 
 
+class LinePart(NamedTuple):
+	path: Tuple[str, ...]  # member path of the image
+	line: object  # the Line it is cut from
+	column: Optional[Tuple[Optional[float], Optional[float]]]  # x interval in dewarped pixels, None = whole line
+
+
+def _table_cell_path(path, column):
+	"""Path of column `column` (1-based) of the table row stored at `path`."""
+	if column < 1:
+		raise AssertionError("columns count from 1")
+	predictor, label, block_id, row = path
+	fields = block_id.split(".")
+	if len(fields) != 4:
+		raise RuntimeError("%s is not a valid table path" % str(path))
+	cell = "%s.%s.%d.%d" % (fields[0], fields[1], int(row) + 1, column)
+	return predictor, label, cell, "0"
+
+
 class LineRewriter:
-	"""Splits table rows into one part per column (ref: lines.py:51-82)."""
+	"""Cuts the rows of table blocks at the column separators found in tables.json."""
 
 	def __init__(self, tables):
-		self._columns = dict(
-			(tuple(k.split("/")), xs) for k, xs in (tables or {}).get("columns", {}).items())
+		separators = (tables or {}).get("columns", {})
+		self._separators = {tuple(block.split("/")): list(xs) for block, xs in separators.items()}
 
-	def _column_path(self, path, column):
-		assert column >= 1
-		predictor, label = path[:2]
-		parts = path[2].split(".")
-		if len(parts) != 4:
-			raise RuntimeError("%s is not a valid table path" % str(path))
-		block, division, _, _ = parts
-		line = 1 + int(path[-1])  # index of the line inside this block division
-		grid = ".".join(map(str, (block, division, line, column)))
-		return predictor, label, grid, str(0)
+	def parts_of(self, path, line):
+		xs = self._separators.get(tuple(path[:3]))
+		if xs is None:
+			yield LinePart(path, line, None)
+			return
+		edges = [None, *xs, None]  # open at both ends of the row
+		for k in range(len(edges) - 1):
+			yield LinePart(_table_cell_path(path, k + 1), line, (edges[k], edges[k + 1]))
 
 	def __call__(self, lines):
-		line_parts = []
-		for path, line in lines.items():
-			line_columns = self._columns.get(path[:3])
-			if line_columns is None:
-				line_parts.append((path, line, None))
-			else:
-				line_columns = [None] + line_columns + [None]
-				for i, (x0, x1) in enumerate(zip(line_columns, line_columns[1:])):
-					line_parts.append((self._column_path(path, 1 + i), line, (x0, x1)))
-		return line_parts
+		return [tuple(part) for path, line in lines.items() for part in self.parts_of(path, line)]
+
+
+_UNSUPPORTED = dict(
+	binarize="--binarize is not part of the GPU line path",
+	do_not_dewarp="--do-not-dewarp: deskewed / warped line images are not part of the GPU line path")
 
 
 class LineExtractor:
 	def __init__(self, tables, line_height, options, min_confidence=0.5):
-		self._options = options
+		if line_height is None:
+			raise AssertionError("line_height is required")
+		if str(options.get("binarize") or "").strip():
+			raise click.UsageError(_UNSUPPORTED["binarize"])
+		if options.get("do_not_dewarp"):
+			raise click.UsageError(_UNSUPPORTED["do_not_dewarp"])
 		self._line_height = line_height
-		assert self._line_height is not None
-		if self._options.get("binarize", "").strip():
-			raise click.UsageError("--binarize is not part of the GPU line path")
-		if self._options.get("do_not_dewarp"):
-			raise click.UsageError(
-				"--do-not-dewarp: deskewed / warped line images are not part of the GPU line path")
 		self._min_confidence = min_confidence
 		self._rewriter = LineRewriter(tables)
 
 	@staticmethod
 	def options(f):
-		options = [
-			click.option(
-				'--binarize', type=str, default="",
-				help="binarization algorithm to use (e.g. otsu), or empty if none"),
-			click.option('--do-not-dewarp', default=False, is_flag=True, help='do not dewarp line images'),
-			click.option('--do-not-deskew', default=False, is_flag=True, help='do not deskew line images'),
-		]
-		return functools.reduce(lambda x, opt: opt(x), options, f)
+		for decorate in (
+				click.option('--do-not-deskew', default=False, is_flag=True, help='do not deskew line images'),
+				click.option('--do-not-dewarp', default=False, is_flag=True, help='do not dewarp line images'),
+				click.option(
+					'--binarize', type=str, default="",
+					help="binarization algorithm to use (e.g. otsu), or empty if none")):
+			f = decorate(f)
+		return f
 
-	def __call__(self, lines, ignored=None):
-		"""{path: Line} -> [(path, PIL.Image)] in the reference's order."""
-		if ignored is not None:
-			lines = dict((k, v) for k, v in lines.items() if not ignored(tuple(k[:2])))
-		filtered_lines = []
+	def plan(self, lines, ignored=None):
+		"""The parts to render, in the order of `lines`: lines of ignored (predictor, label) classes and lines
+		below the confidence threshold are dropped, table rows are cut into cells."""
+		parts = []
 		for path, line in lines.items():
+			if ignored is not None and ignored(tuple(path[:2])):
+				continue
 			if line.confidence < self._min_confidence:
 				logging.info("skipping line %s with confidence %.1f" % (str(path), line.confidence))
 				continue
-			filtered_lines.append((path, line))
-		line_parts = self._rewriter(dict(filtered_lines))
-		if not line_parts:
+			parts.extend(self._rewriter.parts_of(path, line))
+		return parts
+
+	def __call__(self, lines, ignored=None):
+		"""{path: Line} -> [(path, PIL.Image)]"""
+		parts = self.plan(lines, ignored)
+		if not parts:
 			return []
-		page = line_parts[0][1].block.page
-		assert all(line.block.stage.is_dewarped for _, line, _ in line_parts)
-		images = dewarped_line_images(
-			page, [(line, column) for _, line, column in line_parts], self._line_height)
-		return [(path, im) for (path, _, _), im in zip(line_parts, images)]
+		if not all(part.line.block.stage.is_dewarped for part in parts):
+			raise AssertionError("line images are cut from dewarped stages only")
+		page = parts[0].line.block.page
+		images = dewarped_line_images(page, [(part.line, part.column) for part in parts], self._line_height)
+		return [(part.path, image) for part, image in zip(parts, images)]

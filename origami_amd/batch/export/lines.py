@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""`python -m origami_amd.batch.export.lines DATA_PATH` — export the dewarped line images of every page
-(ref: origami/batch/export/lines.py:18-105; same options, same images.lines.dewarped.zip)."""
+"""`python -m origami_amd.batch.export.lines DATA_PATH` — the dewarped line images of every page as PNG files in
+one zip per page.
+
+Shared with the reference's stage of the same name (origami/batch/export/lines.py:18-105): the command and its
+options, the inputs (lines + tables of the RELIABLE stage), the output file name
+`images.lines[.dewarped|.deskewed][.binarized].zip`, member names `<path joined by "/" or "-">.png`, PNG written
+with optimize=True."""
 
 import io
 from pathlib import Path
@@ -12,43 +17,46 @@ from ..core.lines import LineExtractor
 from ..core.processor import Processor
 
 
+def output_name(options):
+	"""Name of the zip for a combination of rendering options."""
+	if not options["do_not_dewarp"]:
+		geometry = ["dewarped"]
+	elif not options["do_not_deskew"]:
+		geometry = ["deskewed"]
+	else:
+		geometry = []
+	tone = ["binarized"] if options.get("binarize") else []
+	return ".".join(["images", "lines", *geometry, *tone, "zip"])
+
+
+def png_bytes(image):
+	data = io.BytesIO()
+	image.save(data, format="png", optimize=True)
+	return data.getvalue()
+
+
 class LineExtractionProcessor(Processor):
 	def __init__(self, options):
 		super().__init__(options)
 		self._options = dict(options)
-		self._output = None
+		self._output = DebuggingArtifact(output_name(self._options))
 
 	@property
 	def output(self):
-		if self._output is None:
-			name = ["images", "lines"]
-			if not self._options["do_not_dewarp"]:
-				name.append("dewarped")
-			elif not self._options["do_not_deskew"]:
-				name.append("deskewed")
-			if self._options.get("binarize", False):
-				name.append("binarized")
-			name.append("zip")
-			self._output = DebuggingArtifact(".".join(name))
 		return self._output
 
 	def artifacts(self):
 		return [
 			("input", Input(Artifact.LINES, Artifact.TABLES, stage=Stage.RELIABLE)),
-			("output", Output(self.output)),
+			("output", Output(self._output)),
 		]
 
 	def process(self, page_path: Path, input, output):
-		lines = input.lines.by_path
-		extractor = LineExtractor(input.tables, self._options["line_height"], self._options)
-		images = extractor(lines)
-		zip_sep = "-" if self._options["flat"] else "/"
-		with output.write_zip_file(self.output) as zf:
-			for stem, im in images:
-				with io.BytesIO() as f:
-					im.save(f, format='png', optimize=True)
-					data = f.getvalue()
-				zf.writestr("%s.png" % zip_sep.join(stem), data)
+		extract = LineExtractor(input.tables, self._options["line_height"], self._options)
+		joiner = "-" if self._options["flat"] else "/"
+		with output.write_zip_file(self._output) as zf:
+			for path, image in extract(input.lines.by_path):
+				zf.writestr(joiner.join(path) + ".png", png_bytes(image))
 
 
 @click.command()
@@ -60,8 +68,7 @@ class LineExtractionProcessor(Processor):
 def export_lines(data_path, **kwargs):
 	""" Export line images from all document images in DATA_PATH. Needs
 	information from previous batches. """
-	processor = LineExtractionProcessor(kwargs)
-	processor.traverse(data_path)
+	LineExtractionProcessor(kwargs).traverse(data_path)
 
 
 if __name__ == "__main__":
