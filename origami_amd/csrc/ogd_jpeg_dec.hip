@@ -328,8 +328,16 @@ walk:
       }
     }
   }
-  // (one atomic per walk, here: an atomicAdd inside the divergent decode loop above made neighbouring lanes store
-  // wrong coefficient values in launches of more than 65536 chunks — measured, not understood; gfx950, ROCm 7.2)
+  // One atomic per walk, AFTER the loop.  With `atomicAdd(rst_check, 1)` inside the divergent loop above, the round-1
+  // form of this kernel (commit 465d566) decoded long three-component streams to wrong pixels, differently on
+  // every run.  Round 2 reproduced it on demand and narrowed it down (tools/jpeg_atomic_variants.py,
+  // profiles/r02/c_jpeg_atomic_probe.log): it is NOT the compiler's atomic optimiser (same fault with
+  // -amdgpu-atomic-optimizer-strategy=None); a plain store in the atomic's place is harmless; the atomic WITH its
+  // return value used, or followed by s_waitcnt 0, is harmless too.  What faults is a no-return global atomic left
+  // in flight while the wave goes on to its next loads and sub-dword coefficient stores (every wait the compiler
+  // placed in that loop is a full vmcnt(0), operands and EXEC handling around the atomic check out in the ISA) —
+  // and only in that code shape: today's loop with the same atomic put back passes.  Rule kept in this library:
+  // no fire-and-forget atomic inside a walk; count in a register, publish once at the end.
   if (WRITE && RST) {
     if (taken) atomicAdd(rst_check, taken);
     if (misplaced) rst_check[1] = 1;

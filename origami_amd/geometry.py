@@ -161,6 +161,29 @@ def _ring_is_valid(r, crosses=None):
 	return not (_segments_cross(r) if crosses is None else crosses)
 
 
+def convex_hull_ring(points):
+	"""Convex hull of a point set as a closed ring, clockwise like GEOS' ConvexHull writes it (what
+	`geom.convex_hull.exterior.coords` holds, up to the starting vertex); None if the points span no area."""
+	pts = sorted(set(map(tuple, np.asarray(points, dtype=np.float64).reshape(-1, 2).tolist())))
+	if len(pts) < 3:
+		return None
+
+	def chain(seq):
+		out = []
+		for p in seq:
+			while len(out) >= 2 and (
+					(out[-1][0] - out[-2][0]) * (p[1] - out[-2][1]) - (out[-1][1] - out[-2][1]) * (p[0] - out[-2][0])) <= 0:
+				out.pop()
+			out.append(p)
+		return out[:-1]
+
+	ccw = chain(pts) + chain(pts[::-1])
+	if len(ccw) < 3:
+		return None
+	cw = ccw[::-1]
+	return np.array(cw + cw[:1], dtype=np.float64)
+
+
 def _point_in_ring(p, r):
 	x, y = p
 	x0, y0 = r[:-1, 0], r[:-1, 1]

@@ -184,15 +184,35 @@ def buffer0_rings(rings):
 	"""rings: [shell, hole, ...] as (n, 2) arrays (closed or not).  Returns the repaired area as a list of polygons,
 	each [shell, hole, ...] of (n, 2) float64 arrays, closed, shells clockwise and holes counter-clockwise as GEOS'
 	buffer writes them.  [] when nothing has depth >= 1."""
+	return overlay([rings], lambda depth: depth[0] >= 1)
+
+
+def intersection_rings(rings_a, rings_b):
+	"""Area common to two polygons ([shell, hole, ...] each), as a list of polygons like buffer0_rings gives.
+	What `a.intersection(b)` keeps of two areal geometries (GEOS OverlayOp: the faces of the noded arrangement
+	that lie in both); ref: origami/batch/detect/compose.py:422 (`poly.intersection(box)`)."""
+	return overlay([rings_a, rings_b], lambda depth: depth[0] >= 1 and depth[1] >= 1)
+
+
+def overlay(groups, keep):
+	"""groups: polygons as ring lists [shell, hole, ...]; every group keeps a depth of its own (see the file
+	comment: +1 inside a shell, -1 inside a hole, rings counted in their own orientation).  The rings of all groups
+	are noded together; the faces whose depth tuple satisfies `keep` are dissolved into polygons."""
 	clean, sign = [], []
-	for k, ring in enumerate(rings):
-		pts = _clean_ring(ring)
-		if pts is None:
-			continue  # GEOS: a ring too short to enclose area adds no curve at distance 0
-		clean.append(pts)
-		sign.append((1 if k == 0 else -1) * (1 if is_ccw_geos(pts) else -1))
+	for g, rings in enumerate(groups):
+		for k, ring in enumerate(rings):
+			pts = _clean_ring(ring)
+			if pts is None:
+				continue  # GEOS: a ring too short to enclose area adds no curve at distance 0
+			clean.append(pts)
+			unit = (1 if k == 0 else -1) * (1 if is_ccw_geos(pts) else -1)
+			sign.append(tuple(unit if j == g else 0 for j in range(len(groups))))
 	if not clean:
 		return []
+	zero = (0,) * len(groups)
+	add = lambda x, y: tuple(a + b for a, b in zip(x, y))
+	sub = lambda x, y: tuple(a - b for a, b in zip(x, y))
+	times = lambda x, m: tuple(a * m for a in x)
 
 	# ---- noding --------------------------------------------------------------------------------------------
 	segments, owner = [], []
@@ -223,9 +243,9 @@ def buffer0_rings(rings):
 				continue
 			# the winding number left of a directed ring segment is one higher than right of it
 			if u < v:
-				delta[(u, v)] = delta.get((u, v), 0) + sign[k]
+				delta[(u, v)] = add(delta.get((u, v), zero), sign[k])
 			else:
-				delta[(v, u)] = delta.get((v, u), 0) - sign[k]
+				delta[(v, u)] = sub(delta.get((v, u), zero), sign[k])
 
 	# ---- half-edges, faces ---------------------------------------------------------------------------------
 	out_edges = {}
@@ -287,22 +307,25 @@ def buffer0_rings(rings):
 		if area[f0] > 0:
 			raise RepairError("no clockwise outer face")
 		p = coords[faces[f0][0][0]]
-		base = sum(sign[k] * _winding(clean[k], p) for k in range(len(clean)) if comp_of_ring[k] != c)
+		base = zero
+		for k in range(len(clean)):
+			if comp_of_ring[k] != c:
+				base = add(base, times(sign[k], _winding(clean[k], p)))
 		depth[f0] = base
 		todo = [f0]
 		while todo:
 			f = todo.pop()
 			for (u, v) in faces[f]:
 				g = face_of[(v, u)]
-				d = delta[(u, v)] if u < v else -delta[(v, u)]  # depth(left of u->v) - depth(right)
+				d = delta[(u, v)] if u < v else times(delta[(v, u)], -1)  # depth(left of u->v) - depth(right)
 				if g not in depth:
-					depth[g] = depth[f] - d
+					depth[g] = sub(depth[f], d)
 					todo.append(g)
-				elif depth[g] != depth[f] - d:
+				elif depth[g] != sub(depth[f], d):
 					raise RepairError("inconsistent face depths")
 
-	# ---- dissolve the faces of depth >= 1 ---------------------------------------------------------------------
-	inside = [depth[f] >= 1 for f in range(len(faces))]
+	# ---- dissolve the faces to keep (buffer(0): depth >= 1) ------------------------------------------------------
+	inside = [bool(keep(depth[f])) for f in range(len(faces))]
 	region = list(range(len(faces)))  # union-find over inside faces that share an edge
 
 	def find(f):
