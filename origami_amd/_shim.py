@@ -82,6 +82,9 @@ SIGNATURES = {
 	"ogd_line_images_u8": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
 		c_void_p]),
+	"ogd_line_images_u8_dev": (c_int, [
+		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+		c_void_p, c_void_p]),
 	"ogd_lattice_delaunay": (c_int, [
 		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
 	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
@@ -414,6 +417,22 @@ class DevicePage:
 			im = out[offsets[k]:offsets[k + 1]].reshape(ys[k], xs[k], C)
 			images.append(im[:, :, 0] if self._squeeze else im)
 		return images
+
+	def line_images_dev(self, nodes, cell, lines, xsteps, ysteps, d_out, interpolation=INTER_LINEAR, stream=None):
+		"""line_images() with the result left on the device: d_out = device address of a buffer of at least the
+		returned offsets[-1] bytes; returns the byte offsets (image l: ysteps[l] x xsteps[l] x C at offsets[l])."""
+		nodes = _c(nodes, np.float32)
+		h, w = nodes.shape[:2]
+		lines = _c(lines, np.float64).reshape(-1, 6)
+		n = len(lines)
+		xs = _c(np.broadcast_to(xsteps, (n,)), np.int32)
+		ys = _c(np.broadcast_to(ysteps, (n,)), np.int32)
+		offsets = np.zeros(n + 1, dtype=np.int64)
+		np.cumsum(xs.astype(np.int64) * ys * self.shape[2], out=offsets[1:])
+		check(load().ogd_line_images_u8_dev(
+			self.handle, _ptr(nodes), h, w, int(cell), _ptr(lines), _ptr(xs), _ptr(ys), n,
+			int(interpolation), c_void_p(int(d_out)), _ptr(offsets), c_void_p(stream) if stream else None))
+		return offsets
 
 	def line_label_counts(self, nodes, cell, lines, xsteps, ysteps, sx, sy):
 		"""This page being a label map: (n, 256) int32 histograms of the labels under each line lattice."""

@@ -227,13 +227,13 @@ int check_line_args(const ogd_page* page, const void* nodes, int h, int w, int s
 
 extern "C" {
 
-int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
-                       const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* out,
-                       const int64_t* offsets) {
-  OGD_REQUIRE(n >= 0, "negative line count");
-  if (n == 0) return OGD_OK;
+// Shared body: validates, stages the node grid and the line records, launches into d_out (device memory of
+// offsets[n] bytes) on `st`; the kernel has been enqueued, not awaited, when this returns OGD_OK.
+static int line_images_launch(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
+                              const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* d_out,
+                              const int64_t* offsets, DevBuf& dn, DevBuf& dl, hipStream_t st) {
   OGD_TRY(check_line_args(page, nodes, h, w, s, lines, xsteps, ysteps, n));
-  OGD_REQUIRE(out && offsets, "null pointer");
+  OGD_REQUIRE(d_out && offsets, "null pointer");
   OGD_REQUIRE(interp == OGD_INTER_NEAREST || interp == OGD_INTER_LINEAR, "interp %d not supported", interp);
   OGD_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
   const int C = page->C;
@@ -241,27 +241,52 @@ int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, i
   int max_x = 0, max_y = 0;
   OGD_TRY(build_line_records(lines, xsteps, ysteps, n, C, offsets, recs, max_x, max_y));
   OGD_TRY(ensure_device());
-  const size_t nb = (size_t)h * w * 2 * sizeof(float), ob = (size_t)offsets[n];
-  DevBuf dn, dl, dout;
+  const size_t nb = (size_t)h * w * 2 * sizeof(float);
   OGD_TRY(dn.alloc(nb));
   OGD_TRY(dl.alloc(recs.size() * sizeof(LineRec)));
-  OGD_TRY(dout.alloc(ob));
-  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
-  OGD_HIP(hipMemcpy(dl.p, recs.data(), recs.size() * sizeof(LineRec), hipMemcpyHostToDevice));
+  // pageable host sources: both copies have left the host buffers when the calls return
+  OGD_HIP(hipMemcpyAsync(dn.p, nodes, nb, hipMemcpyHostToDevice, st));
+  OGD_HIP(hipMemcpyAsync(dl.p, recs.data(), recs.size() * sizeof(LineRec), hipMemcpyHostToDevice, st));
   const dim3 grid((unsigned)((max_x + 63) / 64), (unsigned)((max_y + 3) / 4), (unsigned)n), block(256);
   const float2* dnodes = dn.as<float2>();
   const double inv_s = 1.0 / (double)s;
 #define OGD_LINES(CC, II)                                                                                  \
-  hipLaunchKernelGGL((line_images_kernel<CC, II>), grid, block, 0, nullptr, page->d, page->H, page->W,       \
-                     page->stride, dnodes, h, w, s, inv_s, dl.as<LineRec>(), dout.as<uint8_t>())
+  hipLaunchKernelGGL((line_images_kernel<CC, II>), grid, block, 0, st, page->d, page->H, page->W,            \
+                     page->stride, dnodes, h, w, s, inv_s, dl.as<LineRec>(), d_out)
   if (interp == OGD_INTER_LINEAR) {
     if (C == 1) OGD_LINES(1, OGD_INTER_LINEAR); else if (C == 3) OGD_LINES(3, OGD_INTER_LINEAR); else OGD_LINES(4, OGD_INTER_LINEAR);
   } else {
     if (C == 1) OGD_LINES(1, OGD_INTER_NEAREST); else if (C == 3) OGD_LINES(3, OGD_INTER_NEAREST); else OGD_LINES(4, OGD_INTER_NEAREST);
   }
 #undef OGD_LINES
-  OGD_TRY(check_launch("line_images_kernel"));
+  return check_launch("line_images_kernel");
+}
+
+int ogd_line_images_u8(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
+                       const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* out,
+                       const int64_t* offsets) {
+  OGD_REQUIRE(n >= 0, "negative line count");
+  if (n == 0) return OGD_OK;
+  OGD_REQUIRE(out && offsets, "null pointer");
+  OGD_TRY(ensure_device());
+  const size_t ob = (size_t)offsets[n];
+  DevBuf dn, dl, dout;
+  OGD_TRY(dout.alloc(ob));
+  OGD_TRY(line_images_launch(page, nodes, h, w, s, lines, xsteps, ysteps, n, interp, dout.as<uint8_t>(), offsets, dn,
+                             dl, nullptr));
   OGD_HIP(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+  return OGD_OK;
+}
+
+int ogd_line_images_u8_dev(const ogd_page* page, const float* nodes, int h, int w, int s, const double* lines,
+                           const int32_t* xsteps, const int32_t* ysteps, int n, int interp, uint8_t* d_out,
+                           const int64_t* offsets, void* stream) {
+  OGD_REQUIRE(n >= 0, "negative line count");
+  if (n == 0) return OGD_OK;
+  DevBuf dn, dl;  // node grid and line records: staged through the block cache, free again once the stream is idle
+  OGD_TRY(line_images_launch(page, nodes, h, w, s, lines, xsteps, ysteps, n, interp, d_out, offsets, dn, dl,
+                             as_stream(stream)));
+  OGD_HIP(hipStreamSynchronize(as_stream(stream)));
   return OGD_OK;
 }
 

@@ -67,6 +67,36 @@ def test_line_images_match_oracle(gpu, C, interp):
 	assert bad <= 1e-3 * total, (bad, total)
 
 
+def test_line_images_device_output_equals_host_output(gpu):
+	"""ogd_line_images_u8_dev leaves the images in device memory (for a GPU-resident consumer): same bytes as
+	ogd_line_images_u8, read back through ogd_memcpy_d2h."""
+	import ctypes
+	rng = np.random.default_rng(321)
+	h, w, s = 24, 18, 25
+	nodes = _nodes(rng, h, w, s)
+	page = synth.text_page(rng, (w * s - 30, h * s - 40), channels=3)
+	lines = _lines(rng, 25, w * s, h * s)
+	xsteps = rng.integers(2, 300, size=len(lines)).astype(np.int32)
+	ysteps = np.full(len(lines), 48, dtype=np.int32)
+	lib = gpu.load()
+	with gpu.DevicePage(page) as dp:
+		want = dp.line_images(nodes, s, lines, xsteps, ysteps)
+		total = int(np.sum(xsteps.astype(np.int64) * ysteps) * 3)
+		d_out = ctypes.c_void_p()
+		gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_out), total))
+		try:
+			offsets = dp.line_images_dev(nodes, s, lines, xsteps, ysteps, d_out.value)
+			assert offsets[-1] == total
+			flat = np.empty(total, dtype=np.uint8)
+			gpu.check(lib.ogd_memcpy_d2h(flat.ctypes.data, d_out, total, None))
+			gpu.check(lib.ogd_stream_sync(None))
+		finally:
+			gpu.check(lib.ogd_dev_free(d_out))
+	for k, im in enumerate(want):
+		got = flat[offsets[k]:offsets[k + 1]].reshape(im.shape)
+		np.testing.assert_array_equal(got, im)
+
+
 def test_line_mirror_matches_oracle(gpu):
 	"""Line.warped_grid / dewarped_image / dewarped_line_images (sizes chosen by the rough lattice)."""
 	from origami_amd import block as blk

@@ -47,6 +47,21 @@ print("page %dx%d, %d lines, %.1f Mpx of line images" % (W, H, n, px / 1e6))
 print("upload page: %.1f ms; ogd_line_images_u8 (host in, host out): %.2f ms/page = %.0f Mpx/s" % (
 	(t1 - t0) * 1e3, gpu_s * 1e3, px / gpu_s / 1e6))
 
+# device-output form: the images stay in device memory (no 152 MB device -> host copy)
+import ctypes
+lib = _shim.load()
+d_out = ctypes.c_void_p()
+_shim.check(lib.ogd_dev_alloc(ctypes.byref(d_out), px))
+dp.line_images_dev(nodes, s, geo, xsteps, ysteps, d_out.value)
+t6 = time.perf_counter()
+for _ in range(reps):
+	dp.line_images_dev(nodes, s, geo, xsteps, ysteps, d_out.value)
+t7 = time.perf_counter()
+dev_s = (t7 - t6) / reps
+print("ogd_line_images_u8_dev (host descriptors in, images stay on the device): %.2f ms/page = %.0f Mpx/s" % (
+	dev_s * 1e3, px / dev_s / 1e6))
+_shim.check(lib.ogd_dev_free(d_out))
+
 grid = odw.Grid(nodes, s)
 grid.points_full()
 m = min(n, 40)
