@@ -16,7 +16,7 @@ import click
 
 from ... import _shim
 from ...dewarp import Grid, Samples
-from ...geometry import parse_wkt, to_wkt, to_wkt_many
+from ...geometry import parse_wkt, to_wkt, to_wkt_many, without_repeats
 from ...repair import RepairError
 from ..core.io import Artifact, Input, Output, Stage
 from ..core.processor import Processor
@@ -39,7 +39,7 @@ def dewarped_contours(warped, transformer, min_areas):
 	rings = [r for g in geoms for r in g.rings]
 	warped_rings = transformer.transform_rings(rings)
 	# ... and one for the quadratic part of every ring's validity test (ref: dewarp.py:35)
-	crossing = _shim.rings_self_cross(warped_rings)
+	crossing = _shim.rings_self_cross([without_repeats(r) for r in warped_rings])
 	k = 0
 	kept_names, kept = [], []
 	for name, warped_geom in zip(names, geoms):

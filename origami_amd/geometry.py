@@ -70,9 +70,9 @@ class Geom:
 		return self.valid_given(None)
 
 	def valid_given(self, crossing):
-		"""is_valid with the quadratic part precomputed: crossing[k] tells whether ring k touches or crosses
-		itself (the batch stage gets these flags for all rings of a page from one launch of
-		ogd_rings_self_cross); None computes them here."""
+		"""is_valid with the quadratic part precomputed: crossing[k] tells whether ring k — with repeated
+		consecutive points removed (without_repeats) — touches or crosses itself (the batch stage gets these flags
+		for all rings of a page from one launch of ogd_rings_self_cross); None computes them here."""
 		if self.is_empty:
 			return True
 		if self.geom_type == "LineString":
@@ -149,12 +149,25 @@ def _segments_cross(r):
 	return bool(np.any((proper | touch) & non_adjacent))
 
 
+def without_repeats(r):
+	"""The ring without repeated consecutive points.  GEOS' validity test works on the ring with repeats removed:
+	a vertex written twice is legal, it is not a ring touching itself."""
+	r = np.asarray(r, dtype=np.float64).reshape(-1, 2)
+	if len(r) < 2:
+		return r
+	keep = np.ones(len(r), dtype=bool)
+	keep[1:] = np.any(r[1:] != r[:-1], axis=1)
+	return r if keep.all() else r[keep]
+
+
 def _ring_is_valid(r, crosses=None):
+	"""crosses: the precomputed answer of the quadratic test for without_repeats(r), or None to compute it here."""
 	if len(r) < 4 or not np.all(np.isfinite(r)):
 		return False
 	if not np.array_equal(r[0], r[-1]):
 		return False
-	if np.any(np.all(r[1:] == r[:-1], axis=1)) and len(np.unique(r, axis=0)) < 3:
+	r = without_repeats(r)
+	if len(r) < 4:  # fewer than three distinct corners ("too few points")
 		return False
 	if ring_area_signed(r) == 0:
 		return False

@@ -44,6 +44,18 @@ def _frac(p):
 
 
 def _orient(p, q, r):
+	"""Sign of (q - p) x (r - p), exact: a floating-point evaluation decides when its error bound allows
+	(Shewchuk's orient2d filter), rational arithmetic otherwise.  Points are pairs of Fractions of doubles."""
+	ax, ay = float(q[0]) - float(p[0]), float(q[1]) - float(p[1])
+	bx, by = float(r[0]) - float(p[0]), float(r[1]) - float(p[1])
+	l, m = ax * by, ay * bx
+	det = l - m
+	# the differences above are rounded too: 8 eps covers them and the products (coordinates are doubles)
+	bound = 1.8e-15 * (abs(l) + abs(m))
+	if det > bound:
+		return 1
+	if det < -bound:
+		return -1
 	v = (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
 	return (v > 0) - (v < 0)
 

@@ -94,13 +94,13 @@ def label_map(rng, size, n_classes=4, blocks=24):
 	return np.ascontiguousarray(coarse[np.ix_(ys, xs)])
 
 
-def polygon_rings(rng, size, n, mu=48.0, sigma=0.6, lo=4, hi=400, integer_scale=None):
+def polygon_rings(rng, size, n, mu=48.0, sigma=0.6, lo=4, hi=400, integer_scale=None, valid=True):
 	"""n closed star-shaped rings; vertex counts ~ clip(lognormal(ln mu, sigma), lo, hi).  With
 	integer_scale the vertices are integer label-map pixels times that scale, as contours that
 	come from cv2.findContours are (ref: origami/core/contours.py:59-73, page.py:44-62)."""
 	W, H = size
 	rings = []
-	for _ in range(n):
+	while len(rings) < n:
 		k = int(np.clip(rng.lognormal(np.log(mu), sigma), lo, hi))
 		cx, cy = rng.uniform(0.05 * W, 0.95 * W), rng.uniform(0.05 * H, 0.95 * H)
 		rad = rng.uniform(0.01, 0.05) * min(W, H)
@@ -111,7 +111,11 @@ def polygon_rings(rng, size, n, mu=48.0, sigma=0.6, lo=4, hi=400, integer_scale=
 		pts[:, 1] = pts[:, 1].clip(0, H - 1)
 		if integer_scale is not None:
 			pts = np.round(pts / integer_scale) * integer_scale
-		rings.append(np.vstack([pts, pts[:1]]))
+		ring = np.vstack([pts, pts[:1]])
+		# contour tracing yields simple rings; rounding and clipping a star can fold it onto itself: draw again
+		if valid and not Geom("Polygon", [ring]).is_valid:
+			continue
+		rings.append(ring)
 	return rings
 
 

@@ -19,6 +19,32 @@ from origami_amd.page import Page
 pytestmark = pytest.mark.gpu
 
 
+def _assert_warped_like_oracle(g0, g1, tf):
+	"""g0: a contour as read from contours.0.zip, g1: the stage's output for it.  Every ring must be the
+	oracle's warp of the input ring to 1e-3 px — unless that warped geometry is invalid (a ring that meets itself:
+	synthetic star polygons rounded to label-map pixels sometimes do), in which case the stage must have written its
+	buffer(0) repair (ref: batch/detect/dewarp.py:35-38): a valid geometry that holds exactly what GEOS' depth
+	rule keeps (checked at random points away from the outline)."""
+	from oracle import rings as orings
+	want = odw.transform_rings(tf, g0.rings)
+	trimmed = [geometry.without_repeats(r) for r in want]
+	broken = g0.geom_type == "Polygon" and any(len(r) >= 4 and orings.ring_self_crosses(r) for r in trimmed)
+	if not broken:
+		assert g1.geom_type == g0.geom_type and len(g1.rings) == len(g0.rings)
+		for w, got in zip(want, g1.rings):
+			assert np.abs(w - got).max() < 1e-3
+		return False
+	assert g1.geom_type in ("Polygon", "MultiPolygon") and g1.is_valid
+	rng = np.random.default_rng(len(want[0]))
+	lo, hi = want[0].min(axis=0) - 3, want[0].max(axis=0) + 3
+	for p in rng.uniform(lo, hi, size=(150, 2)):
+		seg = want[0]
+		near = min(np.hypot(*(seg[:-1] + t * (seg[1:] - seg[:-1]) - p).T).min() for t in np.linspace(0, 1, 101))
+		if near > 0.5:
+			assert orings.point_in_polygons(g1.parts, p) == (orings.buffer0_depth(want, p) >= 1)
+	return True
+
+
 def test_dewarp_stage_matches_oracle(gpu, tmp_path):
 	rng = np.random.default_rng(11)
 	size = (600, 800)
@@ -57,9 +83,7 @@ def test_dewarp_stage_matches_oracle(gpu, tmp_path):
 				continue
 			g0 = geometry.parse_wkt(z0.read(name).decode("utf8"))
 			g1 = geometry.parse_wkt(z1.read(name).decode("utf8"))
-			assert g1.geom_type == g0.geom_type and len(g1.rings) == len(g0.rings)
-			for want, got in zip(odw.transform_rings(tf, g0.rings), g1.rings):
-				assert np.abs(want - got).max() < 1e-3
+			_assert_warped_like_oracle(g0, g1, tf)
 
 	# a second run skips the page; --overwrite redoes it
 	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
@@ -110,17 +134,20 @@ def test_dewarp_stage_config0_full_size(gpu, tmp_path):
 		assert sorted(z1.namelist()) == sorted(names) and z1.namelist()[0] == "meta.json"
 		assert z1.read("separators/V/meta.json") == z0.read("separators/V/meta.json")
 		tf = odw.Grid(data, 25).transformer
+		repaired = 0
 		for name in names:
 			if not name.endswith(".wkt"):
 				continue
 			g0 = geometry.parse_wkt(z0.read(name).decode("utf8"))
 			g1 = geometry.parse_wkt(z1.read(name).decode("utf8"))
-			assert g1.geom_type == g0.geom_type and len(g1.rings) == len(g0.rings)
+			if _assert_warped_like_oracle(g0, g1, tf):
+				repaired += 1
+				continue
 			for want, got in zip(odw.transform_rings(tf, g0.rings), g1.rings):
-				assert np.abs(want - got).max() < 1e-3
 				# "warped integer contours bit-exact": rounded coordinates agree off the .5 boundary
 				off_tie = np.abs(want - np.floor(want) - 0.5) > 1e-4
 				assert np.array_equal(np.round(want)[off_tie], np.round(got)[off_tie])
+		assert repaired <= 6  # a handful of the 60 synthetic regions may meet themselves; most must be plain
 
 	# the page every later stage sees (ref: io.py:275-280, page.py:86-88), whole page bit-exact
 	page = Page(page_path, Grid.open(out / "dewarp.zip"))
