@@ -43,7 +43,7 @@ N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is 
 N_POLYGONS = 400
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
-TRAFFIC_JSON = ROOT / "profiles" / "r01" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh)
+TRAFFIC_JSON = ROOT / "profiles" / "r02" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh)
 
 
 def measured_traffic(k2_bytes):
