@@ -240,6 +240,20 @@ int ogd_line_label_counts(const ogd_page* labels, const float* nodes, int h, int
 int ogd_lattice_delaunay(const double* pts, int h, int w, int32_t* simplices, int64_t cap,
                          int64_t* n_simplices, int32_t* hull, int* n_hull, double* transform);
 
+/* ---- Delaunay triangulation of scattered points without Qhull (host code) --------------
+ * ref: origami/core/lingrid.py:286-290 — scipy.interpolate.LinearNDInterpolator builds scipy.spatial.Delaunay
+ * (Qhull) over the samples and over the extrapolation set of lingrid.py:192-250; origami/core/dewarp.py:108-116
+ * and :143-161 reach it five times per page after ogd_lattice_delaunay.
+ * Sweep over the sorted points + Lawson flips, predicates exact for any finite doubles.  pts: [n][2] float64;
+ * simplices: [cap][3] (cap >= 2*n is always enough), positively oriented; transform: NULL or [cap][3][2] in the
+ * layout of scipy.spatial.Delaunay.transform; n_ties: NULL or the number of interior edges whose two triangles
+ * have cocircular vertices (the triangulation is unique, and equal to Qhull's, iff this is 0 — with ties the
+ * caller should run Qhull, whose choice of diagonal cannot be predicted).
+ * Returns OGD_ERR_UNSUPPORTED for n < 3, coincident points or all-collinear input (the caller then runs Qhull,
+ * which decides which twin stays / raises QhullError as the reference expects). */
+int ogd_delaunay_points(const double* pts, int64_t n, int32_t* simplices, int64_t cap,
+                        int64_t* n_simplices, double* transform, int64_t* n_ties);
+
 /* ---- WKT coordinate text (host code) ---------------------------------------------------------------
  * ref: origami/batch/detect/dewarp.py:39 (`geom.wkt`: shapely -> GEOS WKTWriter, trim, 16 significant digits).
  * Ring r (points offsets[r] .. offsets[r+1]-1 of pts [n][2] float64) becomes "(x y, x y, ...)" at

@@ -87,6 +87,8 @@ SIGNATURES = {
 		c_void_p, c_void_p]),
 	"ogd_lattice_delaunay": (c_int, [
 		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
+	"ogd_delaunay_points": (c_int, [
+		c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int64)]),
 	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
 	"ogd_march_shape": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int,
@@ -470,6 +472,21 @@ def lattice_delaunay(points_hw2):
 	check(load().ogd_lattice_delaunay(
 		_ptr(pts), h, w, _ptr(simplices), cap, ctypes.byref(nt), _ptr(hull), ctypes.byref(nh), _ptr(transform)))
 	return simplices[:nt.value], hull[:nh.value], transform[:nt.value]
+
+
+def delaunay_points(points):
+	"""(n, 2) scattered points -> (simplices (nt, 3) int32, transform (nt, 3, 2), n_ties) as scipy.spatial.Delaunay
+	gives them when n_ties == 0; raises OgdError(ERR_UNSUPPORTED) for coincident / collinear / too few points."""
+	pts = _c(points, np.float64)
+	if pts.ndim != 2 or pts.shape[1] != 2:
+		raise ValueError("points must have shape (n, 2)")
+	cap = 2 * len(pts) + 4
+	simplices = np.empty((cap, 3), dtype=np.int32)
+	transform = np.empty((cap, 3, 2), dtype=np.float64)
+	nt, ties = c_int64(0), c_int64(0)
+	check(load().ogd_delaunay_points(
+		_ptr(pts), len(pts), _ptr(simplices), cap, ctypes.byref(nt), _ptr(transform), ctypes.byref(ties)))
+	return simplices[:nt.value], transform[:nt.value], ties.value
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------

@@ -1,0 +1,111 @@
+// Shared by the two host triangulators (ogd_lattice.hip: warped lattices, ogd_delaunay.hip: scattered points):
+// Lawson's edge flips over a triangle soup with adjacency, and scipy's barycentric transforms.
+//
+// Triangles are positively oriented vertex triples T[3t .. 3t+2]; N[3t + k] is the triangle across the edge
+// opposite vertex k of triangle t (-1: hull edge).  A predicate provider P offers
+//   int incircle(int a, int b, int c, int d)   > 0 iff d lies strictly inside the circle through the positively
+//                                              oriented a, b, c; 0 iff the four are cocircular; exact.
+#pragma once
+#include "ogd_common.h"
+#include <cmath>
+#include <vector>
+
+namespace ogd {
+
+// Flips until every edge whose slot (3t + k) is on `stack` (and every edge a flip touches) is locally Delaunay.
+// Cocircular quads keep the diagonal they have.  hull_slot (may be null): per vertex v the slot of the hull edge
+// v -> next(v); kept current when a flip moves a hull edge to another slot.
+template <class P>
+int lawson_flips(const P& L, std::vector<int32_t>& T, std::vector<int32_t>& N, std::vector<int32_t>& stack,
+                 int64_t& flips, int64_t max_flips, int32_t* hull_slot) {
+  while (!stack.empty()) {
+    const int s = stack.back();
+    stack.pop_back();
+    const int t = s / 3, k = s % 3, u = N[s];
+    if (u < 0) continue;
+    const int a = T[3 * t + k], b = T[3 * t + (k + 1) % 3], c = T[3 * t + (k + 2) % 3];
+    int ku = -1;  // vertex of u opposite the shared edge (b, c)
+    for (int j = 0; j < 3; ++j)
+      if (T[3 * u + j] != b && T[3 * u + j] != c) ku = j;
+    if (ku < 0 || N[3 * u + ku] != t) return fail(OGD_ERR_INVALID, "lawson_flips: adjacency corrupt");
+    const int d = T[3 * u + ku];
+    if (L.incircle(a, b, c, d) <= 0) continue;
+    if (++flips > max_flips) return fail(OGD_ERR_INVALID, "lawson_flips: flip limit exceeded");
+    // quad a, b, d, c (positive); diagonal b-c becomes a-d:  t = (a, b, d), u = (a, d, c)
+    const int n_ab = N[3 * t + (k + 2) % 3];  // across (a, b)
+    const int n_ca = N[3 * t + (k + 1) % 3];  // across (c, a)
+    int n_bd = -1, n_dc = -1;                 // u = (d, c, b) in some rotation: across (b, d) and (d, c)
+    for (int j = 0; j < 3; ++j) {
+      if (T[3 * u + j] == c) n_bd = N[3 * u + j];
+      if (T[3 * u + j] == b) n_dc = N[3 * u + j];
+    }
+    T[3 * t + 0] = a; T[3 * t + 1] = b; T[3 * t + 2] = d;
+    N[3 * t + 0] = n_bd; N[3 * t + 1] = u; N[3 * t + 2] = n_ab;
+    T[3 * u + 0] = a; T[3 * u + 1] = d; T[3 * u + 2] = c;
+    N[3 * u + 0] = n_dc; N[3 * u + 1] = n_ca; N[3 * u + 2] = t;
+    auto relink = [&](int nb, int old_t, int new_t) {
+      if (nb < 0) return;
+      for (int j = 0; j < 3; ++j)
+        if (N[3 * nb + j] == old_t) {
+          // the neighbour may touch old_t on one edge only, but after earlier flips it can also border new_t
+          const int x = T[3 * nb + (j + 1) % 3], y = T[3 * nb + (j + 2) % 3];
+          const int* tv = &T[3 * new_t];
+          const bool hx = tv[0] == x || tv[1] == x || tv[2] == x, hy = tv[0] == y || tv[1] == y || tv[2] == y;
+          if (hx && hy) N[3 * nb + j] = new_t;
+        }
+    };
+    relink(n_bd, u, t);
+    relink(n_ca, t, u);
+    if (hull_slot) {  // hull edges run with the triangles' orientation: b -> d, a -> b, d -> c, c -> a
+      if (n_bd < 0) hull_slot[b] = 3 * t + 0;
+      if (n_ab < 0) hull_slot[a] = 3 * t + 2;
+      if (n_dc < 0) hull_slot[d] = 3 * u + 0;
+      if (n_ca < 0) hull_slot[c] = 3 * u + 1;
+    }
+    stack.push_back(3 * t + 0); stack.push_back(3 * t + 2);
+    stack.push_back(3 * u + 0); stack.push_back(3 * u + 1);
+  }
+  return OGD_OK;
+}
+
+// scipy.spatial.Delaunay.transform for nt triangles: rows 0-1 = inverse of [[x0 - x2, x1 - x2], [y0 - y2, y1 - y2]],
+// row 2 = vertex 2; LU with partial pivoting as LAPACK's dgetrf / dgetrs order the operations; NaN where the
+// reciprocal condition number (1-norm) is below 1000 eps (scipy's rcond_limit).  transform: [nt][3][2].
+inline void simplex_transforms(const double* pts, const int32_t* T, int64_t nt, double* transform) {
+  const double rcond_limit = 1000.0 * 2.220446049250313e-16;
+  const double nan = std::nan("");
+  for (int64_t t = 0; t < nt; ++t) {
+    const double* p0 = pts + 2 * (size_t)T[3 * t], *p1 = pts + 2 * (size_t)T[3 * t + 1], *p2 = pts + 2 * (size_t)T[3 * t + 2];
+    const double a00 = p0[0] - p2[0], a01 = p1[0] - p2[0], a10 = p0[1] - p2[1], a11 = p1[1] - p2[1];
+    double* o = transform + 6 * t;
+    o[4] = p2[0];
+    o[5] = p2[1];
+    // scipy passes its row-major T to column-major LAPACK: the factored matrix is M = T^T and the solution
+    // of M X = I, read back row-major, is X^T = T^-1
+    const double m00 = a00, m01 = a10, m10 = a01, m11 = a11;
+    const bool swap = std::fabs(m10) > std::fabs(m00);
+    const double u00 = swap ? m10 : m00, u01 = swap ? m11 : m01, l10n = swap ? m00 : m10, r1 = swap ? m01 : m11;
+    bool ok = u00 != 0.0;
+    double i00 = nan, i01 = nan, i10 = nan, i11 = nan;
+    if (ok) {
+      const double l10 = l10n * (1.0 / u00);
+      const double u11 = r1 - l10 * u01;
+      ok = u11 != 0.0;
+      if (ok) {
+        const double b00 = swap ? 0.0 : 1.0, b10 = swap ? 1.0 : 0.0;  // column 0 of P I (P: the row swap)
+        const double b01 = swap ? 1.0 : 0.0, b11 = swap ? 0.0 : 1.0;  // column 1
+        const double y10 = b10 - l10 * b00, y11 = b11 - l10 * b01;
+        const double x10 = y10 / u11, x11 = y11 / u11;
+        const double x00 = (b00 - u01 * x10) / u00, x01 = (b01 - u01 * x11) / u00;
+        i00 = x00; i01 = x10; i10 = x01; i11 = x11;
+        const double anorm = std::max(std::fabs(m00) + std::fabs(m10), std::fabs(m01) + std::fabs(m11));
+        const double inorm = std::max(std::fabs(x00) + std::fabs(x10), std::fabs(x01) + std::fabs(x11));
+        const double rcond = 1.0 / (anorm * inorm);
+        if (!(rcond >= rcond_limit)) ok = false;
+      }
+    }
+    o[0] = ok ? i00 : nan; o[1] = ok ? i01 : nan; o[2] = ok ? i10 : nan; o[3] = ok ? i11 : nan;
+  }
+}
+
+}  // namespace ogd

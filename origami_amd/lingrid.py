@@ -259,10 +259,20 @@ class InterpolatorFactory:
 
 	@staticmethod
 	def _triangulate(points, values):
-		# Qhull with scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"): the triangulation that
-		# LinearNDInterpolator builds internally (ref: lingrid.py:286-290)
-		tri = scipy.spatial.Delaunay(points)
-		return _shim.Triangulation(points, tri.simplices, values, tri.transform)
+		# The triangulation that LinearNDInterpolator builds internally (ref: lingrid.py:286-290).  The Delaunay
+		# triangulation is unique unless four points share an empty circle, so ogd_delaunay_points (exact sweep +
+		# flips, host) returns Qhull's simplices at a fraction of the time; with cocircular ties, coincident or
+		# collinear points it is Qhull itself, scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"), that decides.
+		try:
+			simplices, transform, ties = _shim.delaunay_points(points)
+		except _shim.OgdError as e:
+			if e.status != _shim.ERR_UNSUPPORTED:
+				raise
+			ties = -1
+		if ties != 0:
+			tri = scipy.spatial.Delaunay(points)
+			simplices, transform = tri.simplices, tri.transform
+		return _shim.Triangulation(points, simplices, values, transform)
 
 	@property
 	def interpolator(self):

@@ -308,3 +308,131 @@ def test_lattice_delaunay_rejects_what_it_cannot_do():
 	with pytest.raises(_shim.OgdError) as e:
 		_shim.lattice_delaunay(huge)
 	assert e.value.status == _shim.ERR_UNSUPPORTED
+
+
+# ---- ogd_delaunay_points: scattered points without Qhull (host) ---------------------------------------------------
+
+def _field_like_points(rng, n):
+	"""Samples as the flow stage writes them: points strung along text lines and separators."""
+	lines = rng.uniform([200, 200], [5800, 7800], size=(n // 10 + 1, 2))
+	t = rng.uniform(-300, 300, size=(len(lines), 10, 1))
+	d = np.stack([np.cos(rng.normal(0, 0.03, len(lines))), np.sin(rng.normal(0, 0.03, len(lines)))], axis=-1)
+	return (lines[:, None, :] + t * d[:, None, :]).reshape(-1, 2)[:n]
+
+
+def _extrapolation_set(rng, shape):
+	nodes = _warped_lattice(rng, *shape).reshape(-1, 2).astype(np.float64)
+	vals = list(rng.uniform(0, 1, len(nodes)))
+	bounds = (nodes[:, 0].min(), nodes[:, 1].min(), nodes[:, 0].max(), nodes[:, 1].max())
+	return np.asarray(olin.Factory(list(nodes), vals, bounds).extra_pts, dtype=np.float64)
+
+
+@pytest.mark.parametrize("kind,n", [
+	("uniform", 3), ("uniform", 4), ("uniform", 7), ("uniform", 500), ("uniform", 6000), ("clustered", 3000),
+	("field", 1500), ("extrapolation", (12, 9)), ("extrapolation", (60, 45)), ("extrapolation", (2, 2))])
+def test_delaunay_points_equals_qhull(kind, n):
+	"""ogd_delaunay_points gives the simplices and barycentric transforms scipy.spatial.Delaunay (Qhull) gives for the
+	point sets the stage triangulates (ref: lingrid.py:286-290): samples, and extrapolation sets whose points
+	sit exactly on the four box sides."""
+	import scipy.spatial
+	from origami_amd import _shim
+	rng = np.random.default_rng(len(kind) * 1000 + (n if isinstance(n, int) else n[0]))
+	if kind == "uniform":
+		pts = rng.uniform([0, 0], [6000, 8000], size=(n, 2))
+	elif kind == "clustered":
+		pts = rng.normal(0, 1, size=(n, 2)) * rng.choice([1.0, 30.0, 900.0], size=(n, 1)) + 3000
+	elif kind == "field":
+		pts = _field_like_points(rng, n)
+	else:
+		pts = _extrapolation_set(rng, n)
+	simplices, transform, ties = _shim.delaunay_points(pts)
+	ref = scipy.spatial.Delaunay(pts)
+	assert ties == 0
+	ours, theirs = _tri_set(simplices), _tri_set(ref.simplices)
+	# Qhull works with a round-off tolerance: where samples strung along one line happen to lie on the hull it
+	# fans its own slivers (area ~ 1e-12 px^2) between that line and the hull edge, where the exact triangulation
+	# has the Delaunay ones.  Either way their transforms are NaN by scipy's rcond rule (below): no query ever
+	# lands in one, the interpolant is the same.
+	extra = np.array(sorted(ours ^ theirs), dtype=np.int64).reshape(-1, 3)
+	eu, ev = pts[extra[:, 1]] - pts[extra[:, 0]], pts[extra[:, 2]] - pts[extra[:, 0]]
+	assert np.all(np.abs(eu[:, 0] * ev[:, 1] - eu[:, 1] * ev[:, 0]) < 1e-8)
+	for i, sx in enumerate(ref.simplices.tolist()):
+		if tuple(sorted(sx)) not in ours:
+			assert np.isnan(ref.transform[i][:2]).all()
+	assert len(extra) == 0 or kind == "field"
+	u, v = pts[simplices[:, 1]] - pts[simplices[:, 0]], pts[simplices[:, 2]] - pts[simplices[:, 0]]
+	assert np.all(u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0] > 0)  # positively oriented
+	lut = {tuple(sorted(s)): i for i, s in enumerate(ref.simplices.tolist())}
+	for i, s in enumerate(simplices.tolist()):
+		if tuple(sorted(s)) not in lut:
+			assert np.isnan(transform[i][:2]).all()
+			continue
+		if i % max(1, len(simplices) // 400):
+			continue
+		j = lut[tuple(sorted(s))]
+		x = pts[s].mean(axis=0)
+
+		def bary(T, verts):
+			c = T[:2] @ (x - T[2])
+			return dict(zip(verts, [c[0], c[1], 1 - c[0] - c[1]]))
+		a, b = bary(transform[i], s), bary(ref.transform[j], ref.simplices[j].tolist())
+		if np.isnan(ref.transform[j]).any():
+			assert np.isnan(transform[i][:2]).all()  # same rcond rule for slivers
+		else:
+			assert max(abs(a[k] - b[k]) for k in s) < 1e-9
+
+
+def _exact_incircle(a, b, c, d):
+	from fractions import Fraction as F
+	rows = []
+	for p in (a, b, c):
+		x, y = F(float(p[0])) - F(float(d[0])), F(float(p[1])) - F(float(d[1]))
+		rows.append((x, y, x * x + y * y))
+	(a0, a1, a2), (b0, b1, b2), (c0, c1, c2) = rows
+	return a0 * (b1 * c2 - b2 * c1) - a1 * (b0 * c2 - b2 * c0) + a2 * (b0 * c1 - b1 * c0)
+
+
+def test_delaunay_points_is_exact_on_nearly_cocircular_points():
+	"""Points on a circle moved by single ulps, plus nearly collinear triples: every interior edge of the result is
+	locally Delaunay in rational arithmetic, and the reported ties are exactly the cocircular edges."""
+	from origami_amd import _shim
+	rng = np.random.default_rng(5)
+	ang = np.sort(rng.uniform(0, 2 * np.pi, 40))
+	ring = 1000 + 300 * np.stack([np.cos(ang), np.sin(ang)], axis=-1)
+	ring = np.nextafter(ring, ring + rng.choice([-1.0, 1.0], ring.shape))
+	line = np.stack([np.linspace(100, 1900, 30), np.linspace(100, 1900, 30) * 0.5 + 7], axis=-1)
+	line[::3] = np.nextafter(line[::3], 0)
+	square = np.array([[400.0, 400.0], [400.0, 464.0], [464.0, 400.0], [464.0, 464.0]])  # one exact tie
+	pts = np.vstack([ring, line, square, [[1000.0, 1000.0]]])
+	simplices, _, ties = _shim.delaunay_points(pts)
+	edges = {}
+	for t in simplices.tolist():
+		for k in range(3):
+			edges.setdefault(frozenset((t[k], t[(k + 1) % 3])), []).append(t)
+	exact_ties = 0
+	for e, ts in edges.items():
+		if len(ts) != 2:
+			continue
+		t, u = ts
+		d = [v for v in u if v not in e][0]
+		s = _exact_incircle(pts[t[0]], pts[t[1]], pts[t[2]], pts[d])
+		assert s <= 0, "edge %s is not locally Delaunay" % sorted(e)
+		exact_ties += s == 0
+	assert ties == exact_ties >= 1
+	import scipy.spatial
+	u, v = pts[simplices[:, 1]] - pts[simplices[:, 0]], pts[simplices[:, 2]] - pts[simplices[:, 0]]
+	assert 0.5 * np.sum(u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) == pytest.approx(scipy.spatial.ConvexHull(pts).volume, rel=1e-12)
+
+
+def test_delaunay_points_reports_ties_and_rejects_what_qhull_must_decide():
+	from origami_amd import _shim
+	g = np.stack(np.meshgrid(np.arange(12.0), np.arange(9.0)), axis=-1).reshape(-1, 2)
+	simplices, _, ties = _shim.delaunay_points(g)
+	assert len(simplices) == 2 * 11 * 8 and ties == 11 * 8  # every unit square is a tie
+	for bad in (g[:2], np.vstack([g, g[5:6]]), np.stack([np.arange(5.0), 2 * np.arange(5.0)], axis=-1)):
+		with pytest.raises(_shim.OgdError) as e:
+			_shim.delaunay_points(bad)
+		assert e.value.status == _shim.ERR_UNSUPPORTED
+	with pytest.raises(_shim.OgdError) as e:
+		_shim.delaunay_points(np.array([[0.0, 0.0], [1.0, np.nan], [2.0, 5.0]]))
+	assert e.value.status != _shim.ERR_UNSUPPORTED
