@@ -249,10 +249,13 @@ int ogd_lattice_delaunay(const double* pts, int h, int w, int32_t* simplices, in
  * layout of scipy.spatial.Delaunay.transform; n_ties: NULL or the number of interior edges whose two triangles
  * have cocircular vertices (the triangulation is unique, and equal to Qhull's, iff this is 0 — with ties the
  * caller should run Qhull, whose choice of diagonal cannot be predicted).
- * Returns OGD_ERR_UNSUPPORTED for n < 3, coincident points or all-collinear input (the caller then runs Qhull,
- * which decides which twin stays / raises QhullError as the reference expects). */
+ * twin: NULL or [n]: twin[i] = -1 for a triangulated point, else the index of the coincident point (the lowest
+ * index of its group) that stands for point i, which is then in no simplex (Qhull lists such points as
+ * "coplanar" and keeps one of the group, not necessarily the same one); with NULL coincident points are refused.
+ * Returns OGD_ERR_UNSUPPORTED for fewer than 3 distinct points, all-collinear input (Qhull raises QhullError
+ * there, which the reference catches) and, with twin = NULL, coincident points. */
 int ogd_delaunay_points(const double* pts, int64_t n, int32_t* simplices, int64_t cap,
-                        int64_t* n_simplices, double* transform, int64_t* n_ties);
+                        int64_t* n_simplices, double* transform, int64_t* n_ties, int32_t* twin);
 
 /* ---- WKT coordinate text (host code) ---------------------------------------------------------------
  * ref: origami/batch/detect/dewarp.py:39 (`geom.wkt`: shapely -> GEOS WKTWriter, trim, 16 significant digits).

@@ -88,7 +88,7 @@ SIGNATURES = {
 	"ogd_lattice_delaunay": (c_int, [
 		c_void_p, c_int, c_int, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int), c_void_p]),
 	"ogd_delaunay_points": (c_int, [
-		c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int64)]),
+		c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p]),
 	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
 	"ogd_march_shape": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int,
@@ -474,19 +474,24 @@ def lattice_delaunay(points_hw2):
 	return simplices[:nt.value], hull[:nh.value], transform[:nt.value]
 
 
-def delaunay_points(points):
+def delaunay_points(points, twins=False):
 	"""(n, 2) scattered points -> (simplices (nt, 3) int32, transform (nt, 3, 2), n_ties) as scipy.spatial.Delaunay
-	gives them when n_ties == 0; raises OgdError(ERR_UNSUPPORTED) for coincident / collinear / too few points."""
+	gives them when n_ties == 0; raises OgdError(ERR_UNSUPPORTED) for collinear / too few points and, unless
+	twins=True, for coincident points.  twins=True appends a fourth result: twin (n,) int32, -1 for triangulated
+	points, else the index of the coincident point that stands for this one."""
 	pts = _c(points, np.float64)
 	if pts.ndim != 2 or pts.shape[1] != 2:
 		raise ValueError("points must have shape (n, 2)")
 	cap = 2 * len(pts) + 4
 	simplices = np.empty((cap, 3), dtype=np.int32)
 	transform = np.empty((cap, 3, 2), dtype=np.float64)
+	twin = np.empty(len(pts), dtype=np.int32) if twins else None
 	nt, ties = c_int64(0), c_int64(0)
 	check(load().ogd_delaunay_points(
-		_ptr(pts), len(pts), _ptr(simplices), cap, ctypes.byref(nt), _ptr(transform), ctypes.byref(ties)))
-	return simplices[:nt.value], transform[:nt.value], ties.value
+		_ptr(pts), len(pts), _ptr(simplices), cap, ctypes.byref(nt), _ptr(transform), ctypes.byref(ties),
+		_ptr(twin) if twins else None))
+	out = (simplices[:nt.value], transform[:nt.value], ties.value)
+	return out + (twin,) if twins else out
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ from pathlib import Path
 from typing import NamedTuple
 
 from ...geometry import parse_wkt
+from . import fastzip
 
 
 def find_data_path(page_path):
@@ -102,31 +103,43 @@ class Contours(NamedTuple):
 	meta: dict  # {(predictor, label): contents of that folder's meta.json}
 
 
-def read_contours(path, pred_type, open=open):
+def read_members(path, open=open):
+	"""{member name: bytes} of a zip of small members, in archive order (fastzip: one read, no per-member cost)."""
+	with open(path, "rb") as f:
+		return dict(fastzip.ZipReader(f).items())
+
+
+def read_contours(path, pred_type, open=open, members=None, parsed=None):
 	"""The geometries of one predictor type (regions or separators) in a contours zip, in member order, with the
-	per-label meta.json files of the same predictors."""
-	with open(path, "rb") as f, zipfile.ZipFile(f, "r") as zf:
-		head = json.loads(zf.read("meta.json"))
-		# version 1 keyed the predictors by name at the top level, version 2 lists them
-		kinds = head if head["version"] <= 1 else {p["name"]: p for p in head["predictions"]}
-		of_type = {name for name, p in kinds.items() if isinstance(p, dict) and PredictorType[p["type"]] == pred_type}
-		geoms, meta = [], {}
-		for name in zf.namelist():
-			if name.partition("/")[0] not in of_type:
-				continue
-			if name.endswith("/meta.json"):
-				meta[tuple(name.split("/")[:-1])] = json.loads(zf.read(name))
-			elif name.endswith(".wkt"):
-				geoms.append((_member_path(name), parse_wkt(zf.read(name).decode("utf8"))))
+	per-label meta.json files of the same predictors.  members: the archive's contents if the caller holds them
+	already; parsed: a {member name: Geom} cache shared between callers that read the same archive."""
+	if members is None:
+		members = read_members(path, open=open)
+	if parsed is None:
+		parsed = {}
+	head = json.loads(members["meta.json"])
+	# version 1 keyed the predictors by name at the top level, version 2 lists them
+	kinds = head if head["version"] <= 1 else {p["name"]: p for p in head["predictions"]}
+	of_type = {name for name, p in kinds.items() if isinstance(p, dict) and PredictorType[p["type"]] == pred_type}
+	geoms, meta = [], {}
+	for name, data in members.items():
+		if name.partition("/")[0] not in of_type:
+			continue
+		if name.endswith("/meta.json"):
+			meta[tuple(name.split("/")[:-1])] = json.loads(data)
+		elif name.endswith(".wkt"):
+			if name not in parsed:
+				parsed[name] = parse_wkt(data.decode("utf8"))
+			geoms.append((_member_path(name), parsed[name]))
 	return Contours(geoms, meta)
 
 
 class Regions:
 	"""Blocks of a page by member path.  `page` may be a zero-argument callable (see Block)."""
 
-	def __init__(self, path, page, stage, open=open):
+	def __init__(self, path, page, stage, open=open, members=None, parsed=None):
 		from ...block import Block
-		found = read_contours(path, PredictorType.REGION, open=open)
+		found = read_contours(path, PredictorType.REGION, open=open, members=members, parsed=parsed)
 		self._blocks = {where: Block(page, polygon, stage) for where, polygon in found.items}
 
 	@property
@@ -143,7 +156,8 @@ class Lines:
 		if any(b.stage != stage for b in blocks.values()):
 			raise AssertionError("blocks and lines of different stages")
 		self._meta, self._lines = None, {}
-		with open(path, "rb") as f, zipfile.ZipFile(f, "r") as zf:
+		with open(path, "rb") as f:
+			zf = fastzip.ZipReader(f)
 			for name in zf.namelist():
 				if not name.endswith(".json"):
 					raise RuntimeError("illegal file %s in %s." % (name, path))
@@ -237,9 +251,21 @@ class Reader(_PageFiles):
 		return self._once("page", load)
 
 	@property
+	def contour_members(self):
+		"""{member name: bytes} of this page's contours zip, read once (every stage that takes CONTOURS reads
+		the regions, and the dewarp stage then every member again; ref: io.py:275-280)."""
+		return self._once("contour_members", lambda: read_members(self.path(Artifact.CONTOURS), open=self._open))
+
+	@property
+	def contour_geoms(self):
+		"""{member name: Geom} of the .wkt members parsed so far (shared by `regions` and the dewarp stage)."""
+		return self._once("contour_geoms", dict)
+
+	@property
 	def regions(self):
 		return self._once("regions", lambda: Regions(
-			self.path(Artifact.CONTOURS), lambda: self.page, self._stage, open=self._open))
+			self.path(Artifact.CONTOURS), lambda: self.page, self._stage, open=self._open,
+			members=self.contour_members, parsed=self.contour_geoms))
 
 	@property
 	def lines(self):
@@ -341,8 +367,9 @@ class Writer(_PageFiles):
 	def write_zip_file(self, artifact):
 		# deflate level 1: WKT and JSON text shrinks as far as at the default level (485 vs 479 KB for a
 		# broadsheet page's contours) in two thirds of the time; members, order and contents are unchanged
+		# fastzip.ZipWriter: the same archive bytes as zipfile would lay out, assembled without its per-member cost
 		with self._write(self.path(artifact), mode="wb") as f, \
-				zipfile.ZipFile(f, "w", self.compression, compresslevel=1) as zf:
+				fastzip.ZipWriter(f, self.compression, compresslevel=1) as zf:
 			yield zf
 
 	@contextmanager
@@ -351,10 +378,10 @@ class Writer(_PageFiles):
 		(meta.json first, then every <predictor>/<label>/meta.json) are carried over before anything else."""
 		with self.write_zip_file(Artifact.CONTOURS) as out:
 			if copy_meta_from is not None:
-				with zipfile.ZipFile(copy_meta_from.path(Artifact.CONTOURS), "r") as src:
-					folders = [n for n in src.namelist() if n.endswith("/meta.json")]
-					for name in ["meta.json"] + folders:
-						out.writestr(name, src.read(name))
+				src = copy_meta_from.contour_members
+				folders = [n for n in src if n.endswith("/meta.json")]
+				for name in ["meta.json"] + folders:
+					out.writestr(name, src[name])
 			yield out
 
 	@contextmanager

@@ -9,7 +9,6 @@ rings of a page go through the forward transformer in ONE launch of the wavefron
 """
 
 import logging
-import zipfile
 from pathlib import Path
 
 import click
@@ -25,15 +24,16 @@ from ..core.processor import Processor
 def dewarped_contours(warped, transformer, min_areas):
 	"""Yields (member name, WKT bytes) of every contour that survives the warp; ref: dewarp.py:16-39."""
 	names, geoms = [], []
-	with open(warped.path(Artifact.CONTOURS), "rb") as f:
-		with zipfile.ZipFile(f, "r") as zf:
-			for name in zf.namelist():
-				if not name.endswith(".wkt"):
-					continue
-				geom = parse_wkt(zf.read(name).decode("utf8"))
-				assert not geom.is_empty
-				names.append(name)
-				geoms.append(geom)
+	parsed = warped.contour_geoms  # the regions among them were parsed when the page's blocks were read
+	for name, data in warped.contour_members.items():
+		if not name.endswith(".wkt"):
+			continue
+		geom = parsed.get(name)
+		if geom is None:
+			geom = parsed[name] = parse_wkt(data.decode("utf8"))
+		assert not geom.is_empty
+		names.append(name)
+		geoms.append(geom)
 
 	# one ragged launch for all rings of the page
 	rings = [r for g in geoms for r in g.rings]

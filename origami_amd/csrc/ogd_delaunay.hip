@@ -14,8 +14,10 @@
 // doubles (error-free sums and products in the manner of Dekker / Knuth / Shewchuk).  With exact predicates
 // the result IS the Delaunay triangulation, unique unless four points lie on one empty circle; the number of
 // such cocircular interior edges is reported (n_ties) and the caller then asks Qhull, whose choice among equally
-// valid diagonals cannot be predicted.  Coincident points, fewer than three points and all-collinear input
-// return OGD_ERR_UNSUPPORTED for the same reason (Qhull decides which twin stays / raises QhullError).
+// valid diagonals cannot be predicted.  Of coincident points the one with the lowest index is triangulated and the
+// others are reported as its twins (Qhull's "coplanar" points; which twin Qhull keeps cannot be predicted either,
+// so the caller checks that twins carry equal values).  Fewer than three distinct points and all-collinear input
+// return OGD_ERR_UNSUPPORTED (Qhull raises QhullError there, which the reference catches).
 #include "ogd_common.h"
 #include "ogd_lawson.h"
 #include <algorithm>
@@ -166,21 +168,27 @@ struct Points {
 
 #define OGD_UNSUPPORTED(...) return ::ogd::fail(OGD_ERR_UNSUPPORTED, __VA_ARGS__)
 
-int delaunay_points(const double* pts, int64_t n, std::vector<int32_t>& T, int64_t* n_ties) {
-  for (int64_t i = 0; i < 2 * n; ++i)
+int delaunay_points(const double* pts, int64_t n_all, std::vector<int32_t>& T, int64_t* n_ties, int32_t* twin) {
+  for (int64_t i = 0; i < 2 * n_all; ++i)
     if (!std::isfinite(pts[i])) return fail(OGD_ERR_INVALID, "delaunay_points: coordinate %lld is not finite", (long long)i);
-  if (n < 3) OGD_UNSUPPORTED("delaunay_points: %lld points", (long long)n);
   Points L;
   L.p = pts;
-  std::vector<int32_t> o((size_t)n);
+  std::vector<int32_t> o((size_t)n_all);
   std::iota(o.begin(), o.end(), 0);
   std::sort(o.begin(), o.end(), [pts](int32_t a, int32_t b) {
-    return pts[2 * (size_t)a] != pts[2 * (size_t)b] ? pts[2 * (size_t)a] < pts[2 * (size_t)b]
-                                                      : pts[2 * (size_t)a + 1] < pts[2 * (size_t)b + 1];
+    if (pts[2 * (size_t)a] != pts[2 * (size_t)b]) return pts[2 * (size_t)a] < pts[2 * (size_t)b];
+    if (pts[2 * (size_t)a + 1] != pts[2 * (size_t)b + 1]) return pts[2 * (size_t)a + 1] < pts[2 * (size_t)b + 1];
+    return a < b;  // coincident points: the lowest index first
   });
-  for (int64_t i = 1; i < n; ++i)
-    if (pts[2 * (size_t)o[i]] == pts[2 * (size_t)o[i - 1]] && pts[2 * (size_t)o[i] + 1] == pts[2 * (size_t)o[i - 1] + 1])
-      OGD_UNSUPPORTED("delaunay_points: coincident points %d and %d", o[i - 1], o[i]);
+  // coincident points: the first of each group stays, the others are its twins (in no triangle)
+  int64_t n = 0;
+  for (int64_t i = 0; i < n_all; ++i) {
+    const bool same = n > 0 && pts[2 * (size_t)o[i]] == pts[2 * (size_t)o[n - 1]] && pts[2 * (size_t)o[i] + 1] == pts[2 * (size_t)o[n - 1] + 1];
+    if (same && !twin) OGD_UNSUPPORTED("delaunay_points: coincident points %d and %d", o[n - 1], o[i]);
+    if (twin) twin[o[i]] = same ? o[n - 1] : -1;
+    if (!same) o[n++] = o[i];
+  }
+  if (n < 3) OGD_UNSUPPORTED("delaunay_points: %lld distinct points", (long long)n);
 
   // the sorted points up to the first one off the line through o[0], o[1] form a fan around that point
   int64_t k = 2;
@@ -193,7 +201,7 @@ int delaunay_points(const double* pts, int64_t n, std::vector<int32_t>& T, int64
   T.reserve((size_t)6 * n);
   std::vector<int32_t> N;
   N.reserve((size_t)6 * n);
-  std::vector<int32_t> nxt((size_t)n, -1), prv((size_t)n, -1), hslot((size_t)n, -1), stack;
+  std::vector<int32_t> nxt((size_t)n_all, -1), prv((size_t)n_all, -1), hslot((size_t)n_all, -1), stack;
   int64_t flips = 0;
   const int64_t max_flips = n * 256 + 4096;  // Lawson terminates; this only guards a logic error
 
@@ -270,11 +278,11 @@ using namespace ogd;
 extern "C" {
 
 int ogd_delaunay_points(const double* pts, int64_t n, int32_t* simplices, int64_t cap, int64_t* n_simplices,
-                        double* transform, int64_t* n_ties) {
+                        double* transform, int64_t* n_ties, int32_t* twin) {
   OGD_REQUIRE(pts && simplices && n_simplices, "null pointer");
   OGD_REQUIRE(n >= 0 && n < (1 << 30), "%lld points not supported", (long long)n);
   std::vector<int32_t> T;
-  OGD_TRY(delaunay_points(pts, n, T, n_ties));
+  OGD_TRY(delaunay_points(pts, n, T, n_ties, twin));
   const int64_t nt = (int64_t)(T.size() / 3);
   OGD_REQUIRE(nt <= cap, "simplices: room for %lld triangles, need %lld", (long long)cap, (long long)nt);
   std::memcpy(simplices, T.data(), T.size() * sizeof(int32_t));

@@ -34,81 +34,89 @@ def lerp(a, b, x):
 
 
 class Box:
-	"""Outset bounding box that collects the extrapolation samples (ref: lingrid.py:27-165)."""
+	"""Outset bounding box that collects the extrapolation samples (ref: lingrid.py:27-165).
+
+	The samples are kept as array chunks and the projections of a whole hull ring are computed in one go
+	(add_projections): a lattice hull has hundreds of edges, and one numpy call per number was 8 ms of a page's
+	set-up.  The arithmetic per number is unchanged — IEEE double operations in the reference's order; the edge
+	length comes from the same BLAS dot product np.linalg.norm uses on a 2-vector, taken row by row."""
 
 	def __init__(self, minx, miny, maxx, maxy, margin=1):
 		self._minx, self._miny = minx - margin, miny - margin
 		self._maxx, self._maxy = maxx + margin, maxy + margin
 		self._box_size = max(maxx - minx, maxy - miny) + 2 * margin + 1
-		self._rows = []  # [x, y, value...] float64, in insertion order
-		self._tags = []  # per row: set of Border
+		self._chunks = []  # (rows [n][2 + nv] float64, tags [n][4] bool in the order of _SIDES), insertion order
 		self._corners = {}
+
+	_SIDES = (Border.LEFT, Border.RIGHT, Border.TOP, Border.BOTTOM)
+
+	def _table(self):
+		if len(self._chunks) > 1:
+			self._chunks = [(np.vstack([c[0] for c in self._chunks]), np.vstack([c[1] for c in self._chunks]))]
+		return self._chunks[0] if self._chunks else (np.empty((0, 3)), np.empty((0, 4), dtype=bool))
 
 	@property
 	def points(self):
-		for row in self._rows:
+		for row in self._table()[0]:
 			yield row
 		for (cx, cy), val in self._corners.items():
 			yield np.hstack([[cx, cy], val])
 
 	def _intersect(self, p, direction):
-		"""First crossing of the ray p + u * direction (0 <= u <= box_size, |direction| = 1) with
-		the box outline, replacing shapely's LineString/LinearRing intersection (ref:
-		lingrid.py:62-93).  The coordinate of the border that is hit is returned exactly, so the
-		reference's equality test for border membership holds by construction."""
-		px, py = float(p[0]), float(p[1])
-		dx, dy = float(direction[0]), float(direction[1])
-		inside = self._minx < px < self._maxx and self._miny < py < self._maxy
-		if not inside:
+		"""First crossing of the rays p + u * direction (0 <= u <= box_size, |direction| = 1) with the box outline,
+		replacing shapely's LineString/LinearRing intersection (ref: lingrid.py:62-93); p, direction: [n][2].
+		The coordinate of the border that is hit is returned exactly, so the reference's equality test for
+		border membership holds by construction.  Returns x, y, tags [n][4]."""
+		px, py = p[:, 0], p[:, 1]
+		dx, dy = direction[:, 0], direction[:, 1]
+		inside = (self._minx < px) & (px < self._maxx) & (self._miny < py) & (py < self._maxy)
+		if not inside.all():
 			raise ValueError("point %s outside given domain %s" % (
-				p, (self._minx, self._miny, self._maxx, self._maxy)))
-		wall_x = self._maxx if dx > 0 else self._minx
-		wall_y = self._maxy if dy > 0 else self._miny
-		ux = (wall_x - px) / dx if dx != 0 else np.inf
-		uy = (wall_y - py) / dy if dy != 0 else np.inf
-		u = ux if ux <= uy else uy
-		if not u <= self._box_size:
-			raise ValueError("point %s outside given domain, ray along %s does not hit the box" % (
-				p, direction))
-		x = wall_x if ux <= uy else px + u * dx
-		y = wall_y if uy <= ux else py + u * dy
-		tags = set()
-		if x == self._minx:
-			tags.add(Border.LEFT)
-		elif x == self._maxx:
-			tags.add(Border.RIGHT)
-		if y == self._miny:
-			tags.add(Border.TOP)
-		elif y == self._maxy:
-			tags.add(Border.BOTTOM)
-		return tags, x, y
+				p[np.argmin(inside)], (self._minx, self._miny, self._maxx, self._maxy)))
+		wall_x = np.where(dx > 0, self._maxx, self._minx)
+		wall_y = np.where(dy > 0, self._maxy, self._miny)
+		with np.errstate(divide="ignore", invalid="ignore"):
+			ux = np.where(dx != 0, (wall_x - px) / dx, np.inf)
+			uy = np.where(dy != 0, (wall_y - py) / dy, np.inf)
+		by_x = ux <= uy
+		u = np.where(by_x, ux, uy)
+		if not (u <= self._box_size).all():
+			k = np.argmin(u <= self._box_size)
+			raise ValueError("point %s outside given domain, ray along %s does not hit the box" % (p[k], direction[k]))
+		x = np.where(by_x, wall_x, px + u * dx)
+		y = np.where(uy <= ux, wall_y, py + u * dy)
+		left, top = x == self._minx, y == self._miny
+		tags = np.stack([left, ~left & (x == self._maxx), top, ~top & (y == self._maxy)], axis=1)
+		return x, y, tags
 
-	def _add(self, tags, x, y, val):
-		self._rows.append(np.hstack([[x, y], val]).astype(np.float64))
-		self._tags.append(tags)
+	def add_projections(self, a, b):
+		"""Cast both end points of every edge (a[k], b[k]) along the edge normal onto the box, in edge order:
+		a's image, then b's (ref: lingrid.py:95-104).  a, b: [n][2 + nv] rows of [x, y, value...]."""
+		a = np.asarray(a, dtype=np.float64).reshape(len(a), -1)
+		b = np.asarray(b, dtype=np.float64).reshape(len(b), -1)
+		v = a[:, :2] - b[:, :2]
+		length = np.sqrt(np.array([e.dot(e) for e in v]).reshape(len(v)))
+		keep = ~(length < 1e-2)
+		a, b, v = a[keep], b[keep], v[keep]
+		if len(v) == 0:
+			return
+		normal = np.stack([-v[:, 1], v[:, 0]], axis=1)
+		normal /= np.sqrt(np.array([e.dot(e) for e in normal]))[:, np.newaxis]
+		ends = np.stack([a, b], axis=1).reshape(2 * len(a), -1)  # a0, b0, a1, b1, ...
+		x, y, tags = self._intersect(ends[:, :2], np.repeat(normal, 2, axis=0))
+		self._chunks.append((np.column_stack([x, y, ends[:, 2:]]), tags))
 
 	def add_projection(self, a, b):
-		"""Cast both end points of edge (a, b) along the edge normal onto the box
-		(ref: lingrid.py:95-104).  a, b: [x, y, value...]."""
-		a = np.asarray(a, dtype=np.float64)
-		b = np.asarray(b, dtype=np.float64)
-		v = a[:2] - b[:2]
-		if np.linalg.norm(v) < 1e-2:
-			return
-		normal = np.array([-v[1], v[0]])
-		normal /= np.linalg.norm(normal)
-		self._add(*self._intersect(a[:2], normal), a[2:])
-		self._add(*self._intersect(b[:2], normal), b[2:])
-
-	def _on(self, border):
-		return [row for row, tags in zip(self._rows, self._tags) if border in tags]
+		self.add_projections(np.asarray(a, dtype=np.float64)[np.newaxis], np.asarray(b, dtype=np.float64)[np.newaxis])
 
 	def _nearest_to_corner(self, border, f, axis):
-		rows = self._on(border)
-		if not rows:
+		rows, tags = self._table()
+		rows = rows[tags[:, self._SIDES.index(border)]]
+		if not len(rows):
 			return None
 		d = dict(x=0, y=1)[axis]
-		return f(rows, key=lambda pt: pt[d])
+		# the first of equal keys, as Python's min / max over the rows in insertion order
+		return rows[np.argmin(rows[:, d]) if f is min else np.argmax(rows[:, d])]
 
 	def _add_corner(self, cx, cy, p1, p2):
 		# ref: lingrid.py:106-130; the sympy projection is evaluated exactly (rationals), then rounded
@@ -215,7 +223,6 @@ class InterpolatorFactory:
 		except QhullError:
 			self._is_collinear = True  # most probably points are collinear
 
-		head_pts, head_val = [], []
 		if not self._is_collinear:
 			# of coincident input points the reference keeps the value of the last one (dict build)
 			if self._lattice is not None:
@@ -224,22 +231,21 @@ class InterpolatorFactory:
 				last = dict(zip(map(tuple, pts.tolist()), range(len(pts))))
 				idx = [last[tuple(pts[i].tolist())] for i in hull_vertices]
 			ring = np.hstack([pts[hull_vertices], vals[idx].reshape(len(idx), -1)])
-			for a, b in zip(ring, np.roll(ring, -1, axis=0)):
-				box.add_projection(a, b)
-			head_pts = list(ring[:, :2])
-			head_val = list(ring[:, 2:])
+			box.add_projections(ring, np.roll(ring, -1, axis=0))
+			head = ring
 		else:
 			rows = np.hstack([pts, vals.reshape(len(pts), -1)])
-			for a, b in zip(rows, rows[1:]):
-				box.add_projection(a, b)
-				box.add_projection(b, a)
+			# (a, b) then (b, a) for every consecutive pair, as the reference's loop interleaves them
+			box.add_projections(
+				np.stack([rows[:-1], rows[1:]], axis=1).reshape(-1, rows.shape[1]),
+				np.stack([rows[1:], rows[:-1]], axis=1).reshape(-1, rows.shape[1]))
+			head = np.empty((0, rows.shape[1]))
 
 		box.add_corners()
-		rows = list(box.points)
-		extra_pts = head_pts + [r[:2] for r in rows]
-		extra_val = head_val + [r[2:] for r in rows]
-		self._extra_pts = np.array(extra_pts, dtype=np.float64).reshape(-1, 2)
-		self._extra_val = np.array(extra_val, dtype=np.float64).reshape(len(extra_pts), -1)
+		rows = np.array(list(box.points), dtype=np.float64).reshape(-1, head.shape[1])
+		rows = np.vstack([head, rows])
+		self._extra_pts = np.ascontiguousarray(rows[:, :2])
+		self._extra_val = np.ascontiguousarray(rows[:, 2:])
 		if self._squeeze:
 			assert self._extra_val.shape[1] == 1
 			self._extra_val = self._extra_val[:, 0]
@@ -261,10 +267,13 @@ class InterpolatorFactory:
 	def _triangulate(points, values):
 		# The triangulation that LinearNDInterpolator builds internally (ref: lingrid.py:286-290).  The Delaunay
 		# triangulation is unique unless four points share an empty circle, so ogd_delaunay_points (exact sweep +
-		# flips, host) returns Qhull's simplices at a fraction of the time; with cocircular ties, coincident or
-		# collinear points it is Qhull itself, scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"), that decides.
+		# flips, host) returns Qhull's simplices at a fraction of the time; with cocircular ties, coincident points
+		# of different values or collinear points it is Qhull itself, scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"), that decides.
 		try:
-			simplices, transform, ties = _shim.delaunay_points(points)
+			simplices, transform, ties, twin = _shim.delaunay_points(points, twins=True)
+			dropped = np.flatnonzero(twin >= 0)
+			if len(dropped) and not np.array_equal(np.asarray(values)[dropped], np.asarray(values)[twin[dropped]]):
+				ties = -1  # coincident points with different values: the answer depends on which one Qhull keeps
 		except _shim.OgdError as e:
 			if e.status != _shim.ERR_UNSUPPORTED:
 				raise

@@ -436,3 +436,18 @@ def test_delaunay_points_reports_ties_and_rejects_what_qhull_must_decide():
 	with pytest.raises(_shim.OgdError) as e:
 		_shim.delaunay_points(np.array([[0.0, 0.0], [1.0, np.nan], [2.0, 5.0]]))
 	assert e.value.status != _shim.ERR_UNSUPPORTED
+
+
+def test_delaunay_points_merges_coincident_points_on_request():
+	"""The extrapolation set of a lattice holds every hull vertex's two border projections, which can coincide;
+	ogd_delaunay_points then triangulates the first of each group and names it as the twin of the others."""
+	import scipy.spatial
+	from origami_amd import _shim
+	rng = np.random.default_rng(11)
+	pts = rng.uniform(0, 1000, size=(300, 2))
+	pts = np.vstack([pts, pts[[7, 7, 120]]])  # 300, 301 = 7; 302 = 120
+	simplices, _, ties, twin = _shim.delaunay_points(pts, twins=True)
+	assert ties == 0
+	assert twin[300] == 7 and twin[301] == 7 and twin[302] == 120 and np.all(twin[:300] == -1)
+	assert not np.isin(simplices, [300, 301, 302]).any()
+	assert _tri_set(simplices) == _tri_set(scipy.spatial.Delaunay(pts[:300]).simplices)
