@@ -264,6 +264,20 @@ int ogd_delaunay_points(const double* pts, int64_t n, int32_t* simplices, int64_
  * cap >= 52 * n + 2 * nrings bytes is always enough.  No terminating NUL is written. */
 int ogd_wkt_ring_text(const double* pts, const int64_t* offsets, int nrings, char* out, int64_t cap,
                       int64_t* text_offsets);
+/* The reading side, ref: origami/batch/core/io.py:142-144 (shapely.wkt.loads per .wkt member -> GEOS WKTReader).
+ * n texts, text g at text[text_offsets[g] .. text_offsets[g+1]); the byte at text[text_offsets[n]] must be NUL.
+ * POLYGON / LINESTRING / MULTIPOLYGON, optional Z, EMPTY, 2 to 4 numbers per coordinate (x, y kept).
+ * kinds[g]: 0 polygon, 1 linestring, 2 multipolygon.  The rings of all geometries in order: points
+ * ring_offsets[r] .. ring_offsets[r+1]-1 of pts [cap_pts][2]; ring_geom[r] = g; ring_part[r] = index of the
+ * polygon inside a multipolygon (else 0).  A geometry without rings is EMPTY.  Capacities: one point per ','
+ * plus one per text, one ring per '(' are always enough.  Anything else: OGD_ERR_UNSUPPORTED (the caller's
+ * own parser then reports the error as the reference would). */
+int ogd_wkt_parse(const char* text, const int64_t* text_offsets, int n, int8_t* kinds, double* pts,
+                  int64_t cap_pts, int64_t* ring_offsets, int32_t* ring_geom, int32_t* ring_part,
+                  int64_t cap_rings, int64_t* n_rings);
+/* Signed area of every ring in the summation order of GEOS Area::ofRingSigned (what shapely's `geom.area`
+ * adds up, ref: origami/batch/detect/dewarp.py:29-31): out[r] = sum_i (x_i - x_0) * (y_{i-1} - y_{i+1}) / 2. */
+int ogd_rings_area_signed(const double* pts, const int64_t* offsets, int nrings, double* out);
 
 /* ---- the march of the node grid on the device -------------------------------------
  * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),

@@ -90,6 +90,10 @@ SIGNATURES = {
 	"ogd_delaunay_points": (c_int, [
 		c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p]),
 	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+	"ogd_wkt_parse": (c_int, [
+		c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+		POINTER(c_int64)]),
+	"ogd_rings_area_signed": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
 	"ogd_march_shape": (c_int, [
 		c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int,
 		POINTER(c_int), POINTER(c_int)]),
@@ -563,16 +567,24 @@ def tri_eval_ragged(inner, extra, bounds, q, offsets):
 	return out
 
 
+def rings_self_cross_table(flat, offsets):
+	"""One flag per closed ring flat[offsets[r]:offsets[r + 1]]: do two of its non-adjacent segments touch or cross
+	(wavefront per ring)."""
+	flat = _c(flat, np.float64).reshape(-1, 2)
+	offsets = _c(offsets, np.int64)
+	flags = np.zeros(len(offsets) - 1, dtype=np.uint8)
+	if len(flags):
+		check(load().ogd_rings_self_cross(_ptr(flat), _ptr(offsets), len(flags), _ptr(flags)))
+	return flags.astype(bool)
+
+
 def rings_self_cross(rings):
-	"""One flag per closed ring: do two of its non-adjacent segments touch or cross (wavefront per ring)."""
 	if not rings:
 		return np.zeros(0, dtype=bool)
 	offsets = np.zeros(len(rings) + 1, dtype=np.int64)
 	np.cumsum([len(r) for r in rings], out=offsets[1:])
-	flat = _c(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]), np.float64)
-	flags = np.zeros(len(rings), dtype=np.uint8)
-	check(load().ogd_rings_self_cross(_ptr(flat), _ptr(offsets), len(rings), _ptr(flags)))
-	return flags.astype(bool)
+	flat = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings])
+	return rings_self_cross_table(flat, offsets)
 
 
 def tri_rasterize(inner, extra, bounds, x0, y0, step, nx, ny, order="xy", dtype=np.float64):
@@ -638,11 +650,57 @@ def wkt_ring_texts(rings):
 		return []
 	offsets = np.zeros(len(rings) + 1, dtype=np.int64)
 	np.cumsum([len(r) for r in rings], out=offsets[1:])
-	flat = _c(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings]), np.float64)
-	cap = 52 * int(offsets[-1]) + 2 * len(rings)
+	flat = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings])
+	return wkt_ring_texts_table(flat, offsets)
+
+
+def wkt_ring_texts_table(flat, offsets):
+	flat = _c(flat, np.float64).reshape(-1, 2)
+	offsets = _c(offsets, np.int64)
+	nrings = len(offsets) - 1
+	if nrings <= 0:
+		return []
+	cap = 52 * int(offsets[-1]) + 2 * nrings
 	buf = ctypes.create_string_buffer(cap)
-	text_offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+	text_offsets = np.zeros(nrings + 1, dtype=np.int64)
 	check(load().ogd_wkt_ring_text(
-		_ptr(flat), _ptr(offsets), len(rings), ctypes.cast(buf, c_void_p), cap, _ptr(text_offsets)))
-	raw = buf.raw
-	return [raw[a:b].decode("ascii") for a, b in zip(text_offsets[:-1], text_offsets[1:])]
+		_ptr(flat), _ptr(offsets), nrings, ctypes.cast(buf, c_void_p), cap, _ptr(text_offsets)))
+	raw = buf.raw[:int(text_offsets[-1])].decode("ascii")
+	bounds = text_offsets.tolist()
+	return [raw[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+
+
+def wkt_parse(texts):
+	"""Many WKT texts (bytes) in one call -> (kinds (n,) int8 [0 polygon, 1 linestring, 2 multipolygon],
+	pts (N, 2) float64, ring_offsets (R + 1,) int64, ring_geom (R,) int32, ring_part (R,) int32);
+	raises OgdError(ERR_UNSUPPORTED) if any text is not plain POLYGON / LINESTRING / MULTIPOLYGON."""
+	n = len(texts)
+	blob = b"\n".join(texts)
+	text_offsets = np.zeros(n + 1, dtype=np.int64)
+	if n:
+		np.cumsum([len(t) + 1 for t in texts], out=text_offsets[1:])
+		text_offsets[-1] -= 1  # no separator after the last text; bytes objects end in a NUL
+	cap_pts = blob.count(b",") + n + 1
+	cap_rings = blob.count(b"(") + 1
+	kinds = np.zeros(n, dtype=np.int8)
+	pts = np.empty((cap_pts, 2), dtype=np.float64)
+	ring_offsets = np.zeros(cap_rings + 1, dtype=np.int64)
+	ring_geom = np.empty(cap_rings, dtype=np.int32)
+	ring_part = np.empty(cap_rings, dtype=np.int32)
+	nr = c_int64(0)
+	# text g ends where its separator starts: offsets[g + 1] - 1 for all but the last
+	ends = text_offsets.copy()
+	check(load().ogd_wkt_parse(
+		ctypes.cast(ctypes.c_char_p(blob), c_void_p), _ptr(ends), n, _ptr(kinds), _ptr(pts), cap_pts,
+		_ptr(ring_offsets), _ptr(ring_geom), _ptr(ring_part), cap_rings, ctypes.byref(nr)))
+	r = nr.value
+	return kinds, pts[:ring_offsets[r]], ring_offsets[:r + 1], ring_geom[:r], ring_part[:r]
+
+
+def rings_area_signed(flat, offsets):
+	"""Signed areas (GEOS summation order) of the rings flat[offsets[r]:offsets[r + 1]]."""
+	flat = _c(flat, np.float64).reshape(-1, 2)
+	offsets = _c(offsets, np.int64)
+	out = np.zeros(len(offsets) - 1, dtype=np.float64)
+	check(load().ogd_rings_area_signed(_ptr(flat), _ptr(offsets), len(out), _ptr(out)))
+	return out

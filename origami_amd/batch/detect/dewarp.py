@@ -12,57 +12,89 @@ import logging
 from pathlib import Path
 
 import click
+import numpy as np
 
 from ... import _shim
 from ...dewarp import Grid, Samples
-from ...geometry import parse_wkt, to_wkt, to_wkt_many, without_repeats
+from ...geometry import holes_inside, parse_wkt_many, ring_table, rings_valid_table, to_wkt
 from ...repair import RepairError
 from ..core.io import Artifact, Input, Output, Stage
 from ..core.processor import Processor
 
 
 def dewarped_contours(warped, transformer, min_areas):
-	"""Yields (member name, WKT bytes) of every contour that survives the warp; ref: dewarp.py:16-39."""
+	"""Yields (member name, WKT bytes) of every contour that survives the warp; ref: dewarp.py:16-39.
+
+	The page's rings live in one table (geometry.ring_table): one launch warps them (K3 ragged), one launch answers
+	the quadratic part of every ring's validity test (ogd_rings_self_cross), areas and coordinate text come from
+	one host call each; Python touches a contour only to decide its fate, and builds a Geom only for the few
+	that need a repair."""
 	names, geoms = [], []
 	parsed = warped.contour_geoms  # the regions among them were parsed when the page's blocks were read
-	for name, data in warped.contour_members.items():
-		if not name.endswith(".wkt"):
-			continue
-		geom = parsed.get(name)
-		if geom is None:
-			geom = parsed[name] = parse_wkt(data.decode("utf8"))
-		assert not geom.is_empty
-		names.append(name)
-		geoms.append(geom)
+	members = warped.contour_members
+	todo = [name for name in members if name.endswith(".wkt") and name not in parsed]
+	for name, geom in zip(todo, parse_wkt_many([members[name] for name in todo])):
+		parsed[name] = geom
+	for name in members:
+		if name.endswith(".wkt"):
+			assert not parsed[name].is_empty
+			names.append(name)
+			geoms.append(parsed[name])
 
-	# one ragged launch for all rings of the page
-	rings = [r for g in geoms for r in g.rings]
-	warped_rings = transformer.transform_rings(rings)
-	# ... and one for the quadratic part of every ring's validity test (ref: dewarp.py:35)
-	crossing = _shim.rings_self_cross([without_repeats(r) for r in warped_rings])
+	flat, offsets = ring_table([r for g in geoms for r in g.rings])
+	warped_flat = transformer.transform_table(flat, offsets)
+	ring_ok, finite, distinct = rings_valid_table(warped_flat, offsets)  # ref: dewarp.py:35, ring by ring
+	area = np.abs(_shim.rings_area_signed(warped_flat, offsets)).tolist()
+	texts = _shim.wkt_ring_texts_table(warped_flat, offsets)
+	n_pts = np.diff(offsets).tolist()
+	ring_ok, finite, distinct = ring_ok.tolist(), finite.tolist(), distinct.tolist()
+
 	k = 0
-	kept_names, kept = [], []
 	for name, warped_geom in zip(names, geoms):
 		n = len(warped_geom.rings)
-		geom = warped_geom.with_rings(warped_rings[k:k + n])
-		ring_flags = crossing[k:k + n]
+		r0, r1 = k, k + n
 		k += n
+		kind = warped_geom.geom_type
 		path = tuple(name.rsplit(".", 1)[0].split("/"))
-		if geom.is_empty or geom.area < min_areas.get(path[0], 0):
+		if kind == "LineString":
+			a = 0.0
+			valid = n_pts[r0] >= 2 and finite[r0] and distinct[r0] >= 2
+		else:
+			a, r, holes = 0.0, r0, False
+			for part in warped_geom.parts:  # shell minus holes, part by part (GEOS' Polygon::getArea)
+				a += area[r] - sum(area[r + 1:r + len(part)])
+				holes = holes or len(part) > 1
+				r += len(part)
+			valid = all(ring_ok[r0:r1])
+		if n_pts[r0] == 0 or a < min_areas.get(path[0], 0):
 			logging.warning("lost contour %s (A=%.1f) during dewarping." % (path, warped_geom.area))
 			continue
-		if geom.geom_type not in ("Polygon", "LineString"):
-			logging.error("dewarped contour %s is %s" % (name, geom.geom_type))
-		if not geom.valid_given(ring_flags):
+		if kind not in ("Polygon", "LineString"):
+			logging.error("dewarped contour %s is %s" % (name, kind))
+		if valid and kind != "LineString" and holes:
+			r = r0
+			for part in warped_geom.parts:
+				valid = valid and holes_inside([warped_flat[offsets[q]:offsets[q + 1]] for q in range(r, r + len(part))])
+				r += len(part)
+		if not valid:
+			geom = warped_geom.with_rings([warped_flat[offsets[r]:offsets[r + 1]] for r in range(r0, r1)])
 			try:
 				geom = geom.buffer0()  # shapely's geom.buffer(0), ref: dewarp.py:36 (origami_amd/repair.py)
 			except RepairError as e:
 				logging.error("contour %s is invalid and could not be repaired (%s); written as it is." % (name, e))
 			if not geom.is_valid:
 				logging.error("invalid geom %s", to_wkt(geom))
-		kept_names.append(name)
-		kept.append(geom)
-	for name, text in zip(kept_names, to_wkt_many(kept)):
+			text = to_wkt(geom)
+		elif kind == "LineString":
+			text = "LINESTRING " + texts[r0]
+		elif kind == "Polygon":
+			text = "POLYGON (" + ", ".join(texts[r0:r1]) + ")"
+		else:
+			chunks, r = [], r0
+			for part in warped_geom.parts:
+				chunks.append("(" + ", ".join(texts[r:r + len(part)]) + ")")
+				r += len(part)
+			text = "MULTIPOLYGON (" + ", ".join(chunks) + ")"
 		yield name, text.encode("utf8")
 
 

@@ -1,4 +1,4 @@
-// WKT coordinate text of contour rings — host code, no device work.
+// WKT coordinate text of contour rings, written and read, and ring areas — host code, no device work.
 // ref: origami/batch/detect/dewarp.py:39 (`geom.wkt`), origami/batch/core/io.py:565-577 (one .wkt member per
 // contour).  The reference formats through shapely 1.7 -> GEOS 3.8 WKTWriter (C++): trim on, 16 significant
 // digits of the stream's default float format, i.e. printf("%.16g"); "nan" / "inf" / "-inf" spelled as
@@ -6,6 +6,7 @@
 // per-number formatting is native here as it is in the reference.
 #include "ogd_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace ogd {
@@ -24,6 +25,80 @@ static inline int put_number(char* p, double v) {
     return 4;
   }
   return std::snprintf(p, 32, "%.16g", v);
+}
+
+// ---- reading -----------------------------------------------------------------------------------------------------
+// ref: origami/batch/core/io.py:142-144 (`shapely.wkt.loads` on every .wkt member: GEOS' C++ WKTReader).
+
+struct WktCursor {
+  const char* p;
+  const char* end;
+  void blanks() {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+  }
+  bool take(char c) {
+    blanks();
+    if (p < end && *p == c) {
+      ++p;
+      return true;
+    }
+    return false;
+  }
+  bool word(const char* w) {  // case-insensitive keyword
+    blanks();
+    const char* q = p;
+    for (; *w; ++w, ++q)
+      if (q >= end || (*q | 0x20) != *w) return false;
+    if (q < end && ((*q | 0x20) >= 'a' && (*q | 0x20) <= 'z')) return false;
+    p = q;
+    return true;
+  }
+};
+
+struct WktOut {
+  double* pts;
+  int64_t cap_pts, n_pts = 0;
+  int64_t* ring_offsets;
+  int32_t* ring_geom;
+  int32_t* ring_part;
+  int64_t cap_rings, n_rings = 0;
+};
+
+// "(x y [z [m]], ...)" or "()"; false on anything else
+bool parse_ring(WktCursor& c, WktOut& o, int geom, int part) {
+  if (!c.take('(')) return false;
+  if (o.n_rings >= o.cap_rings) return false;
+  o.ring_geom[o.n_rings] = geom;
+  o.ring_part[o.n_rings] = part;
+  if (!c.take(')')) {
+    do {
+      double v[4];
+      int k = 0;
+      for (; k < 4; ++k) {
+        c.blanks();
+        if (c.p >= c.end || *c.p == ',' || *c.p == ')') break;
+        char* stop = nullptr;
+        v[k] = std::strtod(c.p, &stop);  // the buffer ends in NUL (ogd_wkt_parse requires it)
+        if (stop == c.p || stop > c.end) return false;
+        c.p = stop;
+      }
+      if (k < 2 || o.n_pts >= o.cap_pts) return false;
+      o.pts[2 * o.n_pts] = v[0];
+      o.pts[2 * o.n_pts + 1] = v[1];
+      ++o.n_pts;
+    } while (c.take(','));
+    if (!c.take(')')) return false;
+  }
+  o.ring_offsets[++o.n_rings] = o.n_pts;
+  return true;
+}
+
+bool parse_polygon_body(WktCursor& c, WktOut& o, int geom, int part) {
+  if (!c.take('(')) return false;
+  do {
+    if (!parse_ring(c, o, geom, part)) return false;
+  } while (c.take(','));
+  return c.take(')');
 }
 
 }  // namespace ogd
@@ -58,6 +133,72 @@ int ogd_wkt_ring_text(const double* pts, const int64_t* offsets, int nrings, cha
     }
     out[pos++] = ')';
     text_offsets[r + 1] = pos;
+  }
+  return OGD_OK;
+}
+
+int ogd_wkt_parse(const char* text, const int64_t* text_offsets, int n, int8_t* kinds, double* pts, int64_t cap_pts,
+                  int64_t* ring_offsets, int32_t* ring_geom, int32_t* ring_part, int64_t cap_rings,
+                  int64_t* n_rings) {
+  OGD_REQUIRE(n >= 0, "negative text count");
+  OGD_REQUIRE(text_offsets && ring_offsets && n_rings, "null pointer");
+  ring_offsets[0] = 0;
+  *n_rings = 0;
+  if (n == 0) return OGD_OK;
+  OGD_REQUIRE(text && kinds && pts && ring_geom && ring_part, "null pointer");
+  OGD_REQUIRE(text[text_offsets[n]] == 0, "the text buffer must end in a NUL byte");
+  WktOut o;
+  o.pts = pts;
+  o.cap_pts = cap_pts;
+  o.ring_offsets = ring_offsets;
+  o.ring_geom = ring_geom;
+  o.ring_part = ring_part;
+  o.cap_rings = cap_rings;
+  for (int g = 0; g < n; ++g) {
+    OGD_REQUIRE(text_offsets[g + 1] >= text_offsets[g], "text offsets must be non-decreasing");
+    WktCursor c{text + text_offsets[g], text + text_offsets[g + 1]};
+    const int kind = c.word("multipolygon") ? 2 : c.word("polygon") ? 0 : c.word("linestring") ? 1 : -1;
+    bool ok = kind >= 0;
+    if (ok) {
+      kinds[g] = (int8_t)kind;
+      c.word("z");
+      if (!c.word("empty")) {
+        if (kind == 1) {
+          ok = parse_ring(c, o, g, 0);
+        } else if (kind == 0) {
+          ok = parse_polygon_body(c, o, g, 0);
+        } else {
+          ok = c.take('(');
+          for (int part = 0; ok; ++part) {
+            ok = parse_polygon_body(c, o, g, part);
+            if (!ok || !c.take(',')) break;
+          }
+          ok = ok && c.take(')');
+        }
+      }
+      c.blanks();
+      ok = ok && c.p == c.end;
+    }
+    if (!ok) return fail(OGD_ERR_UNSUPPORTED, "WKT text %d not understood (or buffers too small): %.40s", g, text + text_offsets[g]);
+  }
+  *n_rings = o.n_rings;
+  return OGD_OK;
+}
+
+int ogd_rings_area_signed(const double* pts, const int64_t* offsets, int nrings, double* out) {
+  OGD_REQUIRE(nrings >= 0, "negative ring count");
+  if (nrings == 0) return OGD_OK;
+  OGD_REQUIRE(pts && offsets && out, "null pointer");
+  for (int r = 0; r < nrings; ++r) {
+    const int64_t b = offsets[r], n = offsets[r + 1] - b;
+    OGD_REQUIRE(n >= 0, "offsets must be non-decreasing (ring %d)", r);
+    double total = 0.0;
+    if (n >= 3) {
+      const double* q = pts + 2 * b;
+      const double x0 = q[0];
+      for (int64_t i = 1; i < n - 1; ++i) total += (q[2 * i] - x0) * (q[2 * (i - 1) + 1] - q[2 * (i + 1) + 1]);
+    }
+    out[r] = total / 2.0;
   }
   return OGD_OK;
 }

@@ -171,17 +171,24 @@ class Transformer:
 		assert not np.any(np.isnan(pts))
 		return pts[:, 0], pts[:, 1]
 
-	def transform_rings(self, rings):
-		"""All rings of a page in ONE launch, one wavefront per ring (K3 ragged); equivalent to
-		calling the transformer once per ring as shapely.ops.transform does
+	def transform_table(self, flat, offsets):
+		"""All rings of a page — ring r is flat[offsets[r]:offsets[r + 1]] — in ONE launch, one wavefront per ring
+		(K3 ragged); equivalent to calling the transformer once per ring as shapely.ops.transform does
 		(ref: origami/batch/detect/dewarp.py:26)."""
+		if len(flat) == 0:
+			return np.empty((0, 2), dtype=np.float64)
+		out = self._interp.ragged(flat, offsets)
+		assert not np.any(np.isnan(out))
+		return out
+
+	def transform_rings(self, rings):
+		"""transform_table for a list of (n, 2) rings; returns the list of warped rings."""
 		if not rings:
 			return []
 		offsets = np.zeros(len(rings) + 1, dtype=np.int64)
 		np.cumsum([len(r) for r in rings], out=offsets[1:])
 		flat = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings])
-		out = self._interp.ragged(flat, offsets)
-		assert not np.any(np.isnan(out))
+		out = self.transform_table(flat, offsets)
 		return [out[a:b] for a, b in zip(offsets[:-1], offsets[1:])]
 
 

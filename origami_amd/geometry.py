@@ -82,7 +82,7 @@ class Geom:
 		k = 0
 		for part in self.parts:
 			n = len(part)
-			if not all(_ring_is_valid(r, c) for r, c in zip(part, flags[k:k + n])) or not _holes_inside(part):
+			if not all(_ring_is_valid(r, c) for r, c in zip(part, flags[k:k + n])) or not holes_inside(part):
 				return False
 			k += n
 		return True
@@ -207,7 +207,8 @@ def _point_in_ring(p, r):
 	return bool(np.count_nonzero(cond & (x < xi)) % 2)
 
 
-def _holes_inside(rings):
+def holes_inside(rings):
+	"""rings[0] = shell, the rest holes: does every hole start inside the shell."""
 	shell = rings[0]
 	return all(_point_in_ring(h[0], shell) for h in rings[1:])
 
@@ -305,3 +306,80 @@ def to_wkt_many(geoms):
 		else:
 			out.append("LINESTRING " + next(texts))
 	return out
+
+
+# ---- many geometries at once: flat ring tables -------------------------------------------------------------------
+# A page has hundreds of contours of a dozen vertices each; per-ring numpy calls cost more than the arithmetic.
+# The batch stage therefore keeps all rings of a page in one (N, 2) array with ring r at [offsets[r], offsets[r+1])
+# and asks the questions above once per page.
+
+_KINDS = ("Polygon", "LineString", "MultiPolygon")
+
+
+def parse_wkt_many(texts):
+	"""[Geom] for many WKT texts (bytes or str) through one call of ogd_wkt_parse (host code in libogdewarp: what
+	GEOS' WKTReader is to the reference); texts it does not take go through parse_wkt one by one, which raises
+	the errors."""
+	from . import _shim
+	texts = [t.encode("utf8") if isinstance(t, str) else bytes(t) for t in texts]
+	try:
+		kinds, pts, ring_offsets, ring_geom, ring_part = _shim.wkt_parse(texts)
+	except _shim.OgdError as e:
+		if e.status != _shim.ERR_UNSUPPORTED:
+			raise
+		return [parse_wkt(t.decode("utf8")) for t in texts]
+	first = np.searchsorted(ring_geom, np.arange(len(texts) + 1))
+	out = []
+	for g, kind in enumerate(kinds.tolist()):
+		r0, r1 = int(first[g]), int(first[g + 1])
+		rings = [pts[ring_offsets[r]:ring_offsets[r + 1]] for r in range(r0, r1)]
+		if kind == 2:
+			parts = [[] for _ in range(int(ring_part[r1 - 1]) + 1)] if r1 > r0 else []
+			for r, ring in zip(range(r0, r1), rings):
+				parts[ring_part[r]].append(ring)
+			out.append(Geom("MultiPolygon", parts))
+		else:
+			out.append(Geom(_KINDS[kind], rings))
+	return out
+
+
+def ring_table(rings):
+	"""(flat (N, 2) float64, offsets (R + 1,) int64) of a list of rings."""
+	offsets = np.zeros(len(rings) + 1, dtype=np.int64)
+	if rings:
+		np.cumsum([len(r) for r in rings], out=offsets[1:])
+		flat = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 2) for r in rings])
+	else:
+		flat = np.empty((0, 2), dtype=np.float64)
+	return np.ascontiguousarray(flat), offsets
+
+
+def without_repeats_table(flat, offsets):
+	"""without_repeats for every ring of a table."""
+	keep = np.ones(len(flat), dtype=bool)
+	if len(flat) > 1:
+		keep[1:] = np.any(flat[1:] != flat[:-1], axis=1)
+		starts = offsets[:-1]
+		keep[starts[starts < len(flat)]] = True  # the first point of a ring is never a repeat
+	kept_before = np.concatenate([[0], np.cumsum(keep)])
+	return np.ascontiguousarray(flat[keep]), kept_before[offsets].astype(np.int64)
+
+
+def rings_valid_table(flat, offsets, crossing=None):
+	"""_ring_is_valid for every ring of a table (closed polygon rings) -> (valid (R,) bool, and the by-products
+	finite (R,) bool, distinct (R,) number of points left by without_repeats).  crossing: the flags of
+	ogd_rings_self_cross for the rings without repeats, or None to ask the device here."""
+	from . import _shim
+	n = np.diff(offsets)
+	d_flat, d_offsets = without_repeats_table(flat, offsets)
+	nd = np.diff(d_offsets)
+	bad = np.concatenate([[0], np.cumsum(~np.isfinite(flat).all(axis=1))])
+	finite = bad[offsets[1:]] == bad[offsets[:-1]]
+	some = n > 0
+	closed = np.zeros(len(n), dtype=bool)
+	closed[some] = np.all(flat[offsets[:-1][some]] == flat[offsets[1:][some] - 1], axis=1)
+	if crossing is None:
+		crossing = _shim.rings_self_cross_table(d_flat, d_offsets)
+	area = _shim.rings_area_signed(d_flat, d_offsets)
+	valid = (n >= 4) & finite & closed & (nd >= 4) & (area != 0) & ~np.asarray(crossing, dtype=bool)
+	return valid, finite, nd

@@ -184,7 +184,7 @@ def triangulator(request, monkeypatch):
 	if request.param == "qhull":
 		from origami_amd import _shim
 
-		def refuse(points):
+		def refuse(points, twins=False):
 			raise _shim.OgdError(_shim.ERR_UNSUPPORTED, "forced by the test")
 		monkeypatch.setattr(_shim, "delaunay_points", refuse)
 	return request.param

@@ -451,3 +451,53 @@ def test_delaunay_points_merges_coincident_points_on_request():
 	assert twin[300] == 7 and twin[301] == 7 and twin[302] == 120 and np.all(twin[:300] == -1)
 	assert not np.isin(simplices, [300, 301, 302]).any()
 	assert _tri_set(simplices) == _tri_set(scipy.spatial.Delaunay(pts[:300]).simplices)
+
+
+# ---- ring tables: the per-page batch forms of parse_wkt / ring_area_signed / _ring_is_valid ------------------------
+
+def test_parse_wkt_many_equals_parse_wkt():
+	from origami_amd.geometry import parse_wkt, parse_wkt_many, to_wkt
+	rng = np.random.default_rng(8)
+	texts = [
+		"POLYGON ((0 0, 10 0, 10 10, 0 0), (1 1, 2 1, 2 2, 1 1))", " linestring (1.5 2e3, -3 4)\n", "POLYGON EMPTY",
+		"LINESTRING EMPTY", "MULTIPOLYGON (((0 0, 1 0, 1 1, 0 0)), ((5 5, 6 5, 6 6, 5 5), (5.1 5.1, 5.2 5.1, 5.2 5.2, 5.1 5.1)))",
+		"POLYGON Z ((0 0 1, 1 0 1, 1 1 1, 0 0 1))", "LINESTRING (nan inf, -inf 1)", "POLYGON((0 0,1 0,1 1,0 0))"]
+	for ring in synth.polygon_rings(rng, (6000, 8000), 50, mu=20):
+		texts.append(to_wkt(geometry.Geom("Polygon", [ring])))
+	got = parse_wkt_many([t.encode("utf8") for t in texts])
+	for text, g in zip(texts, got):
+		w = parse_wkt(text)
+		assert g.geom_type == w.geom_type and len(g.rings) == len(w.rings) and len(g.parts) == len(w.parts)
+		for a, b in zip(g.rings, w.rings):
+			np.testing.assert_array_equal(a, b)  # both read numbers as strtod does
+		assert [len(p) for p in g.parts] == [len(p) for p in w.parts]
+	# one text the batch reader does not take sends the whole batch through parse_wkt, which raises as before
+	with pytest.raises(ValueError):
+		parse_wkt_many([b"POLYGON ((0 0, 1 0, 1 1, 0 0))", b"POINT (1 2)"])
+	assert parse_wkt_many([]) == []
+
+
+def test_ring_tables_equal_the_per_ring_functions():
+	from origami_amd import _shim, geometry
+	rng = np.random.default_rng(9)
+	rings = synth.polygon_rings(rng, (3000, 4000), 60, mu=25, valid=False)
+	rings.append(np.array([[0.0, 0.0], [4.0, 0.0], [4.0, 0.0], [4.0, 4.0], [4.0, 4.0], [0.0, 0.0]]))  # repeats
+	rings.append(np.array([[0.0, 0.0], [4.0, 4.0], [4.0, 0.0], [0.0, 4.0], [0.0, 0.0]]))  # bow-tie
+	rings.append(np.array([[0.0, 0.0], [4.0, 0.0], [4.0, 4.0], [1.0, 1.0]]))  # open
+	rings.append(np.array([[0.0, 0.0], [4.0, 0.0], [np.nan, 4.0], [0.0, 0.0]]))
+	rings.append(np.array([[0.0, 0.0], [4.0, 0.0], [0.0, 0.0]]))  # too short
+	rings.append(np.array([[0.0, 0.0], [2.0, 0.0], [4.0, 0.0], [0.0, 0.0]]))  # no area
+	rings.append(np.array([[1.0, 1.0], [1.0, 1.0], [1.0, 1.0], [1.0, 1.0]]))
+	rings.append(np.empty((0, 2)))
+	flat, offsets = geometry.ring_table(rings)
+	np.testing.assert_array_equal(
+		_shim.rings_area_signed(flat, offsets), [geometry.ring_area_signed(r) for r in rings])
+	d_flat, d_offsets = geometry.without_repeats_table(flat, offsets)
+	for k, r in enumerate(rings):
+		np.testing.assert_array_equal(d_flat[d_offsets[k]:d_offsets[k + 1]], geometry.without_repeats(r))
+	crossing = [len(r) >= 4 and geometry._segments_cross(geometry.without_repeats(r)) for r in rings]
+	valid, finite, distinct = geometry.rings_valid_table(flat, offsets, crossing=crossing)
+	assert valid.tolist() == [bool(geometry._ring_is_valid(r)) for r in rings]
+	assert valid.sum() > 10 and (~valid).sum() >= 8
+	assert finite.tolist() == [bool(np.all(np.isfinite(r))) for r in rings]
+	assert distinct.tolist() == [len(geometry.without_repeats(r)) for r in rings]
