@@ -19,7 +19,7 @@ from contextlib import contextmanager
 from pathlib import Path
 from typing import NamedTuple
 
-from ...geometry import parse_wkt
+from ...geometry import parse_wkt_many
 from . import fastzip
 
 
@@ -121,15 +121,15 @@ def read_contours(path, pred_type, open=open, members=None, parsed=None):
 	# version 1 keyed the predictors by name at the top level, version 2 lists them
 	kinds = head if head["version"] <= 1 else {p["name"]: p for p in head["predictions"]}
 	of_type = {name for name, p in kinds.items() if isinstance(p, dict) and PredictorType[p["type"]] == pred_type}
+	mine = [name for name in members if name.partition("/")[0] in of_type]
+	todo = [name for name in mine if name.endswith(".wkt") and name not in parsed]
+	for name, geom in zip(todo, parse_wkt_many([members[name] for name in todo])):  # one call for the page
+		parsed[name] = geom
 	geoms, meta = [], {}
-	for name, data in members.items():
-		if name.partition("/")[0] not in of_type:
-			continue
+	for name in mine:
 		if name.endswith("/meta.json"):
-			meta[tuple(name.split("/")[:-1])] = json.loads(data)
+			meta[tuple(name.split("/")[:-1])] = json.loads(members[name])
 		elif name.endswith(".wkt"):
-			if name not in parsed:
-				parsed[name] = parse_wkt(data.decode("utf8"))
 			geoms.append((_member_path(name), parsed[name]))
 	return Contours(geoms, meta)
 

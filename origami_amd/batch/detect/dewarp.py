@@ -9,6 +9,7 @@ rings of a page go through the forward transformer in ONE launch of the wavefron
 """
 
 import logging
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import click
@@ -102,6 +103,7 @@ class DewarpProcessor(Processor):
 	def __init__(self, options):
 		super().__init__(options)
 		self._options = dict(options)
+		self._saver = None
 
 	@property
 	def processor_name(self):
@@ -125,14 +127,24 @@ class DewarpProcessor(Processor):
 
 		grid = Grid.create(page, samples_h, samples_v, grid_res=self._options["grid_cell_size"])
 
-		min_areas = dict(regions=grid.geometry.rel_area(self._options["region_area"]), separators=0)
+		# dewarp.zip is 600 KB of float32 that deflate chews on for 14 ms (zlib releases the GIL): it is written by
+		# a second thread while this one builds the transformer and warps the contours (most of that time is spent
+		# inside libogdewarp, which releases the GIL too).  Either file appears complete or not at all, and a page
+		# with only one of them is redone (Writer.fix_inconsistent), so the order of the two does not matter.
+		def save_grid():
+			with output.dewarping_transform() as f:
+				grid.save(f)
 
-		with output.contours(copy_meta_from=warped) as zf:
-			for name, data in dewarped_contours(warped, grid.transformer, min_areas=min_areas):
-				zf.writestr(name, data)
-
-		with output.dewarping_transform() as f:
-			grid.save(f)
+		if self._saver is None:
+			self._saver = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dewarp-save")
+		saving = self._saver.submit(save_grid)
+		try:
+			min_areas = dict(regions=grid.geometry.rel_area(self._options["region_area"]), separators=0)
+			with output.contours(copy_meta_from=warped) as zf:
+				for name, data in dewarped_contours(warped, grid.transformer, min_areas=min_areas):
+					zf.writestr(name, data)
+		finally:
+			saving.result()
 
 
 @click.command()

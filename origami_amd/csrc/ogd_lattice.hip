@@ -175,9 +175,10 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   for (int i = 0; i < 2 * n; ++i) {
     const double v = pts[i];
     if (!(std::fabs(v) < 1048576.0)) OGD_UNSUPPORTED("coordinate %g outside the exact domain (|x| < 2^20)", v);
-    const double s = std::ldexp(v, 40);
-    if (s != std::nearbyint(s)) OGD_UNSUPPORTED("coordinate %.17g is not a multiple of 2^-40", v);
-    L.q[i] = (int64_t)s;
+    const double s = v * 1099511627776.0;  // 2^40: exact, |s| < 2^60
+    const int64_t k = (int64_t)s;
+    if ((double)k != s) OGD_UNSUPPORTED("coordinate %.17g is not a multiple of 2^-40", v);
+    L.q[i] = k;
   }
   auto id = [w](int i, int j) { return i * w + j; };
 
@@ -186,17 +187,23 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   if (sgn == 0) OGD_UNSUPPORTED("degenerate first lattice cell");
   T.clear();
   T.reserve((size_t)6 * n);
+  // split[cell]: 0 = diagonal a-c, triangles (a, b, c), (a, c, d); 1 = diagonal b-d, triangles (a, b, d), (b, c, d).
+  // A convex cell gets the diagonal that is Delaunay for its own four nodes (a-c on a tie), which leaves the
+  // flips below little to do on a smooth warp.
+  std::vector<uint8_t> split((size_t)(h - 1) * (w - 1));
   for (int i = 0; i + 1 < h; ++i)
     for (int j = 0; j + 1 < w; ++j) {
       int a = id(i, j), b = id(i, j + 1), c = id(i + 1, j + 1), d = id(i + 1, j);
       if (sgn < 0) std::swap(b, d);  // mirrored lattice: (a, d, c, b) is the positive order
-      if (L.orient(a, b, c) > 0 && L.orient(a, c, d) > 0) {
-        T.insert(T.end(), {a, b, c, a, c, d});
-      } else if (L.orient(a, b, d) > 0 && L.orient(b, c, d) > 0) {
+      const bool ac = L.orient(a, b, c) > 0 && L.orient(a, c, d) > 0;
+      const bool bd = L.orient(a, b, d) > 0 && L.orient(b, c, d) > 0;
+      if (!ac && !bd) OGD_UNSUPPORTED("lattice cell (%d, %d) is folded or degenerate", i, j);
+      const bool use_bd = ac && bd ? L.incircle(a, b, c, d) > 0 : bd;
+      split[(size_t)i * (w - 1) + j] = use_bd;
+      if (use_bd)
         T.insert(T.end(), {a, b, d, b, c, d});
-      } else {
-        OGD_UNSUPPORTED("lattice cell (%d, %d) is folded or degenerate", i, j);
-      }
+      else
+        T.insert(T.end(), {a, b, c, a, c, d});
     }
 
   // 2. outline in positive order
@@ -268,31 +275,40 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   const int nt = (int)(T.size() / 3);
   std::vector<int32_t> N((size_t)3 * nt, -1);
   {
-    // Nearly every edge joins lattice neighbours: hi - lo is 1, w - 1, w or w + 1, so (lo, which of the four)
-    // addresses a table directly; only the few edges inside the hull pockets go through a sort.
+    // Inside the lattice the neighbour across each cell side follows from the two cells' splits.  With the corners
+    // named a, b, c, d in positive order, side ab faces the neighbour's side cd and side bc its side da; the slot
+    // (triangle, opposite vertex) that holds a side: split 0: ab (t0, 2), bc (t0, 0), cd (t1, 0), da (t1, 1);
+    // split 1: ab (t0, 2), bc (t1, 2), cd (t1, 0), da (t0, 1).  The diagonal joins t0 and t1.
+    // Only the outline's sides and the triangles of the hull pockets are matched by sorting.
+    static const int8_t side_tri[2][4] = {{0, 0, 1, 1}, {0, 1, 1, 0}}, side_slot[2][4] = {{2, 0, 0, 1}, {2, 2, 0, 1}};
     struct HalfEdge { uint64_t key; int32_t slot; };
     std::vector<HalfEdge> he;
-    std::vector<int32_t> first((size_t)4 * n, -1);  // -1: not seen, -2: already paired, else the first slot
-    for (int t = 0; t < nt; ++t)
+    const int cw = w - 1, ch = h - 1;
+    // neighbour cell across side ab, bc, cd, da as (di, dj); mirrored lattices have b below a instead of right of it
+    const int di[2][4] = {{-1, 0, 1, 0}, {0, 1, 0, -1}}, dj[2][4] = {{0, 1, 0, -1}, {-1, 0, 1, 0}};
+    const int mir = sgn < 0;
+    for (int i = 0; i < ch; ++i)
+      for (int j = 0; j < cw; ++j) {
+        const int c = i * cw + j, sp = split[c];
+        N[3 * (2 * c) + (sp ? 0 : 1)] = 2 * c + 1;
+        N[3 * (2 * c + 1) + (sp ? 1 : 2)] = 2 * c;
+        for (int side = 0; side < 4; ++side) {
+          const int slot = 3 * (2 * c + side_tri[sp][side]) + side_slot[sp][side];
+          const int ni = i + di[mir][side], nj = j + dj[mir][side];
+          if (ni < 0 || nj < 0 || ni >= ch || nj >= cw) {  // outline: a pocket triangle or nothing
+            const int t = slot / 3, k = slot % 3;
+            const uint32_t x = (uint32_t)T[3 * t + (k + 1) % 3], y = (uint32_t)T[3 * t + (k + 2) % 3];
+            he.push_back({((uint64_t)std::min(x, y) << 32) | std::max(x, y), slot});
+            continue;
+          }
+          const int nc = ni * cw + nj, nsp = split[nc], nside = (side + 2) % 4;
+          N[slot] = 2 * nc + side_tri[nsp][nside];
+        }
+      }
+    for (int t = 2 * ch * cw; t < nt; ++t)
       for (int k = 0; k < 3; ++k) {
-        const uint32_t a = (uint32_t)T[3 * t + (k + 1) % 3], b = (uint32_t)T[3 * t + (k + 2) % 3];
-        const uint32_t lo = std::min(a, b), hi = std::max(a, b), diff = hi - lo;
-        const int code = diff == 1u ? 0 : diff == (uint32_t)w - 1u ? 1 : diff == (uint32_t)w ? 2 : diff == (uint32_t)w + 1u ? 3 : -1;
-        const int32_t slot = 3 * t + k;
-        if (code < 0 || w < 3) {  // w = 2: the four differences are not distinct
-          he.push_back({((uint64_t)lo << 32) | hi, slot});
-          continue;
-        }
-        int32_t& f = first[(size_t)4 * lo + code];
-        if (f == -1) {
-          f = slot;
-        } else if (f >= 0) {
-          N[f] = slot / 3;
-          N[slot] = f / 3;
-          f = -2;
-        } else {
-          OGD_UNSUPPORTED("edge shared by three triangles");
-        }
+        const uint32_t x = (uint32_t)T[3 * t + (k + 1) % 3], y = (uint32_t)T[3 * t + (k + 2) % 3];
+        he.push_back({((uint64_t)std::min(x, y) << 32) | std::max(x, y), 3 * t + k});
       }
     std::sort(he.begin(), he.end(), [](const HalfEdge& x, const HalfEdge& y) { return x.key < y.key; });
     for (size_t k = 0; k + 1 < he.size(); ++k)
@@ -305,10 +321,26 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   }
 
   // 6. Lawson flips until every interior edge is locally Delaunay
-  std::vector<int32_t> stack;
-  stack.reserve((size_t)3 * nt);
+  // The first look at every interior edge is independent of the others: done on a few threads, and only the
+  // edges that fail go on the flip stack (a flip pushes the edges whose quadrilateral it changed).
+  std::vector<int32_t> edges;
+  edges.reserve((size_t)3 * nt / 2);
   for (int s = 3 * nt - 1; s >= 0; --s)
-    if (N[s] > s / 3) stack.push_back(s);
+    if (N[s] > s / 3) edges.push_back(s);
+  std::vector<uint8_t> bad(edges.size(), 0);
+  parallel_ranges((int64_t)edges.size(), 16384, [&](int64_t e0, int64_t e1) {
+    for (int64_t e = e0; e < e1; ++e) {
+      const int s = edges[e], t = s / 3, k = s % 3, u = N[s];
+      const int a = T[3 * t + k], b = T[3 * t + (k + 1) % 3], c = T[3 * t + (k + 2) % 3];
+      int d = -1;
+      for (int j = 0; j < 3; ++j)
+        if (T[3 * u + j] != b && T[3 * u + j] != c) d = T[3 * u + j];
+      bad[e] = d < 0 || L.incircle(a, b, c, d) > 0;
+    }
+  });
+  std::vector<int32_t> stack;
+  for (size_t e = 0; e < edges.size(); ++e)
+    if (bad[e]) stack.push_back(edges[e]);
   int64_t flips = 0;
   const int64_t max_flips = (int64_t)nt * 64 + 1024;  // Lawson terminates; this only guards a logic error
   OGD_TRY(lawson_flips(L, T, N, stack, flips, max_flips, nullptr));

@@ -7,10 +7,29 @@
 //                                              oriented a, b, c; 0 iff the four are cocircular; exact.
 #pragma once
 #include "ogd_common.h"
+#include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 namespace ogd {
+
+// fn(begin, end) over [0, n) on up to four threads (the calling one included); the per-page set-up of the batch stage
+// is host-bound and these loops are independent per element.  Small n runs inline.
+template <class F>
+void parallel_ranges(int64_t n, int64_t grain, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t want = std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n / std::max<int64_t>(grain, 1));
+  if (want <= 1) {
+    fn((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t step = (n + want - 1) / want;
+  for (int64_t k = 1; k < want; ++k) pool.emplace_back(fn, k * step, std::min(n, (k + 1) * step));
+  fn((int64_t)0, std::min(n, step));
+  for (auto& t : pool) t.join();
+}
 
 // Flips until every edge whose slot (3t + k) is on `stack` (and every edge a flip touches) is locally Delaunay.
 // Cocircular quads keep the diagonal they have.  hull_slot (may be null): per vertex v the slot of the hull edge
@@ -74,7 +93,8 @@ int lawson_flips(const P& L, std::vector<int32_t>& T, std::vector<int32_t>& N, s
 inline void simplex_transforms(const double* pts, const int32_t* T, int64_t nt, double* transform) {
   const double rcond_limit = 1000.0 * 2.220446049250313e-16;
   const double nan = std::nan("");
-  for (int64_t t = 0; t < nt; ++t) {
+  parallel_ranges(nt, 16384, [=](int64_t t_begin, int64_t t_end) {
+  for (int64_t t = t_begin; t < t_end; ++t) {
     const double* p0 = pts + 2 * (size_t)T[3 * t], *p1 = pts + 2 * (size_t)T[3 * t + 1], *p2 = pts + 2 * (size_t)T[3 * t + 2];
     const double a00 = p0[0] - p2[0], a01 = p1[0] - p2[0], a10 = p0[1] - p2[1], a11 = p1[1] - p2[1];
     double* o = transform + 6 * t;
@@ -106,6 +126,7 @@ inline void simplex_transforms(const double* pts, const int32_t* T, int64_t nt, 
     }
     o[0] = ok ? i00 : nan; o[1] = ok ? i01 : nan; o[2] = ok ? i10 : nan; o[3] = ok ? i11 : nan;
   }
+  });
 }
 
 }  // namespace ogd

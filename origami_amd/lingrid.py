@@ -228,8 +228,7 @@ class InterpolatorFactory:
 			if self._lattice is not None:
 				idx = list(hull_vertices)  # a lattice that passed ogd_lattice_delaunay has no coincident nodes
 			else:
-				last = dict(zip(map(tuple, pts.tolist()), range(len(pts))))
-				idx = [last[tuple(pts[i].tolist())] for i in hull_vertices]
+				idx = [int(np.flatnonzero((pts[:, 0] == pts[i, 0]) & (pts[:, 1] == pts[i, 1]))[-1]) for i in hull_vertices]
 			ring = np.hstack([pts[hull_vertices], vals[idx].reshape(len(idx), -1)])
 			box.add_projections(ring, np.roll(ring, -1, axis=0))
 			head = ring

@@ -211,7 +211,7 @@ def test_tri_eval_matches_scipy(gpu, n, vector, triangulator):
 	_close(got_f(q32), want_f(q32), same_bits=bits)
 
 
-def test_tri_eval_collinear_and_errors(gpu):
+def test_tri_eval_collinear_and_errors(gpu, triangulator):
 	from origami_amd.lingrid import InterpolatorFactory, lininterp
 	pts = [np.array([100.0, 100.0]), np.array([200.0, 150.0]), np.array([300.0, 200.0])]
 	vals = [0.01, 0.02, 0.04]
@@ -221,7 +221,7 @@ def test_tri_eval_collinear_and_errors(gpu):
 	assert got_fac.is_collinear
 	rng = np.random.default_rng(0)
 	q = rng.uniform([0, 0], [600, 800], size=(1000, 2))
-	_close(got_fac.interpolator(q), want_f(q))
+	_close(got_fac.interpolator(q), want_f(q), same_bits=triangulator == "qhull")
 	with pytest.raises(ValueError, match="not enough values"):
 		lininterp(pts[:1], vals[:1], bounds)
 
