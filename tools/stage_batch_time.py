@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Throughput (iii) of SURVEY §8d: the `dewarp` batch stage end to end (directory walk, artifact I/O,
 grid construction, contour warp, zip output) on synthetic broadsheet page directories, one worker on one GPU.
-usage: stage_batch_time.py [n_pages n_polygons [W H [workers]]]   (workers > 0: spawned workers, all on GPU 0 of a one-GPU box)   (never bench.py's `value`)"""
+usage: stage_batch_time.py [n_pages n_polygons [W H [workers[,workers...]]]]   (workers > 0: spawned workers, all on GPU 0 of a one-GPU box; a list times the stage once per count on the same pages)   (never bench.py's `value`)"""
 import cProfile
+import os
 import pstats
 import shutil
 import sys
@@ -21,7 +22,8 @@ def main():
 	n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 	n_poly = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 	W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6000, 8000)
-	workers = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+	worker_counts = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
+	workers = worker_counts[0]
 
 	_shim.init(0)
 	root = Path(tempfile.mkdtemp(prefix="ogd_stage_"))
@@ -31,11 +33,16 @@ def main():
 		first = synth.write_page_dir(root, "page0000", rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
 		for k in range(1, n_pages):  # same pixels (the stage reads only the size), own warp / flow / contours
 			page = root / ("page%04d.png" % k)
-			shutil.copyfile(first, page)
+			try:
+				os.link(first, page)  # the stage reads only the size of the page image
+			except OSError:
+				shutil.copyfile(first, page)
 			synth.write_page_inputs(page, rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_poly)
+			if k % 16 == 0:
+				print("  page %d written" % k, flush=True)
 		print("wrote %d page directories %dx%d, %d polygons each, in %.1f s" % (n_pages, W, H, n_poly, time.perf_counter() - t0))
 
-		def run(overwrite):
+		def run(overwrite, workers=workers):
 			args = [str(root), "--lock-strategy", "NONE", "--plain"] + (["--overwrite"] if overwrite else [])
 			if workers:
 				args += ["--gpus", str(workers)]
@@ -45,11 +52,16 @@ def main():
 			return time.perf_counter() - t
 
 		dt = run(False)
-		print("first pass : %.3f s = %.1f ms/page (includes context creation and first-use costs)" % (dt, 1e3 * dt / n_pages))
+		print("first pass : %.3f s = %.1f ms/page (includes context creation and first-use costs)" % (dt, 1e3 * dt / n_pages), flush=True)
 		dt = run(True)
 		mp = n_pages * W * H / 1e6
 		print("second pass: %.3f s = %.1f ms/page = %.0f MP/s (page megapixels per second through the stage)" % (
 			dt, 1e3 * dt / n_pages, mp / dt))
+		if len(worker_counts) > 1:
+			for n in worker_counts[1:]:
+				dt = run(True, n)
+				print("%2d workers : %.3f s = %.1f ms/page = %.0f MP/s" % (n, dt, 1e3 * dt / n_pages, mp / dt), flush=True)
+			return
 		# the stage that writes annotation.dewarped.jpg from dewarp.zip (ref: origami/batch/utils/dewarp.py)
 		from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
 
