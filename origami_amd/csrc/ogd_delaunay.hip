@@ -169,8 +169,12 @@ struct Points {
 #define OGD_UNSUPPORTED(...) return ::ogd::fail(OGD_ERR_UNSUPPORTED, __VA_ARGS__)
 
 int delaunay_points(const double* pts, int64_t n_all, std::vector<int32_t>& T, int64_t* n_ties, int32_t* twin) {
-  for (int64_t i = 0; i < 2 * n_all; ++i)
+  for (int64_t i = 0; i < 2 * n_all; ++i) {
     if (!std::isfinite(pts[i])) return fail(OGD_ERR_INVALID, "delaunay_points: coordinate %lld is not finite", (long long)i);
+    // the incircle polynomial has degree 4: its error-free products must neither overflow nor underflow
+    const double m = std::fabs(pts[i]);
+    if (m > 0x1p200 || (m != 0.0 && m < 0x1p-200)) OGD_UNSUPPORTED("delaunay_points: coordinate %g outside the exact domain", pts[i]);
+  }
   Points L;
   L.p = pts;
   std::vector<int32_t> o((size_t)n_all);

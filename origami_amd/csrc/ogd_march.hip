@@ -52,9 +52,10 @@ static FieldView field_view(const ogd_tri* inner, const ogd_tri* extra, double p
 }
 
 // Field.get (ref: dewarp.py:118-122): unit direction at a float32 position.
-__device__ __forceinline__ float2 field_dir(const FieldView& f, float px, float py) {
+// `hint`: the triangles that answered the walk's previous point (start a walk with (-1, -1)).
+__device__ __forceinline__ float2 field_dir(const FieldView& f, float px, float py, int2& hint) {
   double ang = f.phi0;
-  if (!f.constant) eval_point<1>(f.inner, f.has_inner, f.extra, f.b, (double)px, (double)py, &ang);
+  if (!f.constant) eval_point_hint<1>(f.inner, f.has_inner, f.extra, f.b, (double)px, (double)py, &ang, hint);
   const float a = (float)ang;  // np.cos(angles, dtype=float32) casts first
   return make_float2((float)cos((double)a), (float)sin((double)a));
 }
@@ -78,14 +79,21 @@ __global__ __launch_bounds__(EXT_THREADS) void march_extent_kernel(FieldView fh,
   const int max_steps = 2 * (1 + (axis == 0 ? W : H));
   for (int i = threadIdx.x; i < n; i += EXT_THREADS)
     pts[i] = axis == 0 ? make_float2(0.f, (float)(i * s)) : make_float2((float)(i * s), 0.f);
+  int2 hints[EXT_MAX_PTS / EXT_THREADS];  // one per point this thread owns
+#pragma unroll
+  for (int k = 0; k < EXT_MAX_PTS / EXT_THREADS; ++k) hints[k] = make_int2(-1, -1);
   int n_steps = 1;
   while (true) {
     int any = 0;
     for (int i = threadIdx.x; i < n; i += EXT_THREADS) any |= (axis == 0 ? pts[i].x : pts[i].y) < limit;
     if (!__syncthreads_or(any) || n_steps >= max_steps) break;
-    for (int i = threadIdx.x; i < n; i += EXT_THREADS) {  // each thread owns its points: no barrier needed
-      const float2 p = pts[i];
-      pts[i] = euler_step(p, field_dir(f, p.x, p.y), (float)s);
+#pragma unroll
+    for (int slot = 0; slot < EXT_MAX_PTS / EXT_THREADS; ++slot) {  // each thread owns its points: no barrier needed
+      const int i = threadIdx.x + slot * EXT_THREADS;
+      if (i < n) {
+        const float2 p = pts[i];
+        pts[i] = euler_step(p, field_dir(f, p.x, p.y, hints[slot]), (float)s);
+      }
     }
     ++n_steps;
   }
@@ -99,9 +107,10 @@ __global__ __launch_bounds__(64) void march_rows_kernel(FieldView fh, int n_rows
   if (gy >= n_rows) return;
   float2 p = make_float2(0.f, (float)(gy * s));
   float2* row = gh + (size_t)gy * n_cols;
+  int2 hint = make_int2(-1, -1);
   for (int gx = 0; gx < n_cols; ++gx) {
     row[gx] = p;
-    p = euler_step(p, field_dir(fh, p.x, p.y), (float)s);
+    p = euler_step(p, field_dir(fh, p.x, p.y, hint), (float)s);
   }
 }
 
@@ -167,9 +176,10 @@ __global__ __launch_bounds__(256) void march_columns_kernel(FieldView fv, const 
   const float len = step_len[gx / slice_len];
   float2 p0 = gh[gx];  // row 0
   const int n_seg = n_cols - 1;
+  int2 hint = make_int2(-1, -1);
   for (int gy = 0; gy + 1 < n_rows; ++gy) {
     if (lane == 0) hv[(size_t)gy * n_cols + gx] = p0;
-    float2 p1 = euler_step(p0, field_dir(fv, p0.x, p0.y), len);
+    float2 p1 = euler_step(p0, field_dir(fv, p0.x, p0.y, hint), len);
     const double p0x = (double)p0.x, p0y = (double)p0.y;
     const double rx = (double)p1.x - p0x, ry = (double)p1.y - p0y;
     bool found = false;

@@ -482,6 +482,31 @@ struct BindDevice {
   }
 };
 
+// Triangle record t = {T00, T01, T10, T11, r0, r1, v0[nv], v1[nv], v2[nv]}: the barycentric transform as given
+// (scipy's Delaunay.transform layout) or, without one, the plain inverse of the edge matrix (columns v0 - v2, v1 - v2).
+__global__ __launch_bounds__(256) void tri_records_kernel(const double2* __restrict__ pts, const int32_t* __restrict__ simplices,
+                                                          const double* __restrict__ transform, const double* __restrict__ vals,
+                                                          int nv, int nt, double* __restrict__ recs, int rec) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const int32_t s0 = simplices[3 * (size_t)t], s1 = simplices[3 * (size_t)t + 1], s2 = simplices[3 * (size_t)t + 2];
+  double* r = recs + (size_t)t * rec;
+  if (transform) {
+    const double* T = transform + 6 * (size_t)t;
+    for (int k = 0; k < 6; ++k) r[k] = T[k];
+  } else {
+    const double2 p0 = pts[s0], p1 = pts[s1], p2 = pts[s2];
+    const double ax = __dsub_rn(p0.x, p2.x), bx = __dsub_rn(p1.x, p2.x);
+    const double ay = __dsub_rn(p0.y, p2.y), by = __dsub_rn(p1.y, p2.y);
+    const double det = __dsub_rn(__dmul_rn(ax, by), __dmul_rn(bx, ay));
+    r[0] = by / det; r[1] = -bx / det; r[2] = -ay / det; r[3] = ax / det;
+    r[4] = p2.x; r[5] = p2.y;
+  }
+  const int32_t s[3] = {s0, s1, s2};
+  for (int j = 0; j < 3; ++j)
+    for (int k = 0; k < nv; ++k) r[6 + j * nv + k] = vals[(size_t)s[j] * nv + k];
+}
+
 static int check_pair(const ogd_tri* inner, const ogd_tri* extra) {
   OGD_REQUIRE(extra != nullptr, "extra triangulation is NULL");
   OGD_REQUIRE(inner == nullptr || inner->nv == extra->nv, "inner/extra value widths differ (%d vs %d)",
@@ -508,30 +533,12 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
   OGD_TRY(ensure_device());
 
   const int rec = 6 + 3 * nv;
-  std::vector<double> recs((size_t)nt * rec);
   double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
   for (int i = 0; i < n; ++i) {
     const double x = pts[2 * i], y = pts[2 * i + 1];
     OGD_REQUIRE(std::isfinite(x) && std::isfinite(y), "point %d is not finite", i);
     bx0 = std::min(bx0, x); bx1 = std::max(bx1, x);
     by0 = std::min(by0, y); by1 = std::max(by1, y);
-  }
-  for (int t = 0; t < nt; ++t) {
-    const int32_t* s = simplices + 3 * (size_t)t;
-    double* r = recs.data() + (size_t)t * rec;
-    if (transform) {
-      const double* T = transform + 6 * (size_t)t;
-      for (int k = 0; k < 6; ++k) r[k] = T[k];
-    } else {
-      // edge matrix columns = v0 - v2, v1 - v2; r = v2  (scipy Delaunay.transform layout)
-      const double ax = pts[2 * s[0]] - pts[2 * s[2]], bx = pts[2 * s[1]] - pts[2 * s[2]];
-      const double ay = pts[2 * s[0] + 1] - pts[2 * s[2] + 1], by = pts[2 * s[1] + 1] - pts[2 * s[2] + 1];
-      const double det = ax * by - bx * ay;
-      r[0] = by / det; r[1] = -bx / det; r[2] = -ay / det; r[3] = ax / det;
-      r[4] = pts[2 * s[2]]; r[5] = pts[2 * s[2] + 1];
-    }
-    for (int j = 0; j < 3; ++j)
-      for (int k = 0; k < nv; ++k) r[6 + j * nv + k] = vals[(size_t)s[j] * nv + k];
   }
 
   // bucket grid: about four cells per triangle (most cells then lie inside one triangle and a query tests one
@@ -554,10 +561,20 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
   h->gnx = gnx; h->gny = gny; h->gx0 = bx0; h->gy0 = by0;
   h->inv_cw = 1.0 / cw; h->inv_ch = 1.0 / ch;
   auto build = [&]() -> int {
-    OGD_TRY(upload(&h->d_rec, recs));
-    DevBuf dpts, dsimp, dcursor, dscalars, dbig;
+    DevBuf dpts, dsimp, dcursor, dscalars, dbig, dtransform, dvals;
     OGD_TRY(dpts.alloc((size_t)n * 2 * sizeof(double)));
     OGD_TRY(dsimp.alloc((size_t)nt * 3 * sizeof(int32_t)));
+    OGD_TRY(dvals.alloc((size_t)n * nv * sizeof(double)));
+    OGD_HIP(hipMemcpy(dvals.p, vals, (size_t)n * nv * sizeof(double), hipMemcpyHostToDevice));
+    if (transform) {
+      OGD_TRY(dtransform.alloc((size_t)nt * 6 * sizeof(double)));
+      OGD_HIP(hipMemcpy(dtransform.p, transform, (size_t)nt * 6 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    {
+      const size_t bytes = (size_t)nt * rec * sizeof(double);
+      hipError_t e = hipMalloc((void**)&h->d_rec, bytes);
+      if (e != hipSuccess) return fail(OGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
     OGD_TRY(dcursor.alloc((size_t)ncell * sizeof(int)));
     OGD_TRY(dscalars.alloc(32));  // long long total | int max_cell | int nbig | int nlong
     OGD_TRY(dbig.alloc((size_t)nt * sizeof(int)));
@@ -569,6 +586,11 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     unsigned long long* d_total = dscalars.as<unsigned long long>();
     int* d_nbig = reinterpret_cast<int*>(dscalars.as<char>() + 12);
     const dim3 tgrid((unsigned)((nt + 255) / 256)), tblock(256);
+    // the triangle records are assembled on the device (a broadsheet Transformer has 157 k of them, 15 MB)
+    hipLaunchKernelGGL(tri_records_kernel, tgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
+                       transform ? dtransform.as<double>() : (const double*)nullptr, dvals.as<double>(), nv, nt,
+                       h->d_rec, rec);
+    OGD_TRY(check_launch("tri_records_kernel"));
     hipLaunchKernelGGL(bucket_scatter_kernel<false>, tgrid, tblock, 0, nullptr, dpts.as<double2>(),
                        dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, d_total,
                        dbig.as<int>(), d_nbig);

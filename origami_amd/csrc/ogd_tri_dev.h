@@ -87,6 +87,26 @@ __device__ __forceinline__ bool tri_locate(const TriView& t, double x, double y,
   return false;
 }
 
+// tri_locate for a walk: `hint` is the triangle that held the walk's previous point (-1: none).  It is tried first —
+// its record is one cached 72-byte read instead of three dependent ones (cell, list, record), and a step of one
+// grid cell stays inside the same triangle three times out of four.  Strictly inside a triangle the answer does
+// not depend on how the triangle was found; on a shared edge (within eps) the neighbour may answer, which agrees
+// to the last bits (the interpolant is continuous).
+template <int NV>
+__device__ __forceinline__ bool tri_locate_hint(const TriView& t, double x, double y, double* out, int& hint) {
+  if (hint >= 0 && tri_try<NV>(t.rec + (size_t)hint * (6 + 3 * NV), x, y, out)) return true;
+  const int c = cell_of(t, x, y);
+  const int b = t.cell_start[c], e = t.cell_start[c + 1];
+  for (int k = b; k < e; ++k) {
+    const int tri = t.cell_tris[k];
+    if (tri_try<NV>(t.rec + (size_t)tri * (6 + 3 * NV), x, y, out)) {
+      hint = tri;
+      return true;
+    }
+  }
+  return false;
+}
+
 __device__ __forceinline__ double clipd(double v, double lo, double hi) {
   // numpy.clip = minimum(maximum(v, lo), hi); NaN propagates
   if (v != v) return v;
@@ -102,6 +122,21 @@ __device__ __forceinline__ void eval_point(const TriView& inner, int has_inner, 
   }
   if (has_inner && tri_locate<NV>(inner, x, y, out)) return;
   if (tri_locate<NV>(extra, x, y, out)) return;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[k] = nan;
+}
+
+// eval_point along a walk; hint.x / hint.y: see tri_locate_hint (inner / extra triangulation).
+template <int NV>
+__device__ __forceinline__ void eval_point_hint(const TriView& inner, int has_inner, const TriView& extra,
+                                                const Bounds& b, double x, double y, double* out, int2& hint) {
+  if (b.clip) {
+    x = clipd(x, b.minx, b.maxx);
+    y = clipd(y, b.miny, b.maxy);
+  }
+  if (has_inner && tri_locate_hint<NV>(inner, x, y, out, hint.x)) return;
+  if (tri_locate_hint<NV>(extra, x, y, out, hint.y)) return;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll
   for (int k = 0; k < NV; ++k) out[k] = nan;

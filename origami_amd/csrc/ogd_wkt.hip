@@ -11,7 +11,76 @@
 
 namespace ogd {
 
+// printf("%.16g") for the magnitudes page coordinates have, 1e-4 <= |v| < 1e15, without printf: the decimal point
+// is placed by comparing against exact powers of ten, the 16 digits are round-half-even(m * 10^p / 2^s) in 128-bit
+// integers (v = m * 2^-s exactly, p <= 20), which is the exact decimal expansion of the double correctly rounded —
+// what glibc prints.  Returns 0 for anything else (the caller then asks snprintf).
+static inline int put_fixed16(char* out, double v) {
+  static const double P10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+  static const double N10[5] = {1e0, 1e-1, 1e-2, 1e-3, 1e-4};  // only 1e0 is exact: used as a first guess, checked below
+  const double a = std::fabs(v);
+  if (!(a >= 1e-4 && a < 1e15)) return 0;
+  int k;  // decimal digits in front of the point (<= 0: zeros behind it)
+  if (a >= 1.0) {
+    k = 1;
+    while (k < 16 && a >= P10[k]) ++k;
+  } else {
+    k = 0;
+    while (k > -4 && a < N10[1 - k]) --k;  // a guess within one of the truth
+  }
+  uint64_t bits;
+  std::memcpy(&bits, &a, sizeof bits);
+  const int be = (int)(bits >> 52);
+  if (be == 0) return 0;
+  const uint64_t m = (bits & ((1ull << 52) - 1)) | (1ull << 52);
+  const int s = 1075 - be;  // a = m * 2^-s; a < 2^50 -> s >= 3; a >= 1e-4 -> s <= 66
+  typedef unsigned __int128 u128;
+  uint64_t digits = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const int p = 16 - k;  // 1 .. 20
+    u128 t = m;
+    for (int i = 0; i < p; ++i) t *= 10;  // < 2^53 * 10^20 < 2^120
+    const u128 q = t >> s, rem = t - (q << s), half = (u128)1 << (s - 1);
+    uint64_t n = (uint64_t)q;
+    if (rem > half || (rem == half && (n & 1))) ++n;
+    if (n >= 10000000000000000ull) {  // 17 digits: the point sits one place further right
+      ++k;
+      continue;
+    }
+    if (n < 1000000000000000ull) {  // 15 digits: one place further left
+      --k;
+      continue;
+    }
+    digits = n;
+    break;
+  }
+  if (!digits || k > 15 || k < -3) return 0;  // |v| rounds to 1e15 (scientific in %g) or the guesses failed
+  char d[16];
+  for (int i = 15; i >= 0; --i) {
+    d[i] = (char)('0' + digits % 10);
+    digits /= 10;
+  }
+  int last = 15;
+  while (last > 0 && d[last] == '0') --last;  // %g drops trailing zeros
+  char* o = out;
+  if (std::signbit(v)) *o++ = '-';
+  if (k > 0) {
+    for (int i = 0; i < k; ++i) *o++ = d[i];  // digits past `last` in front of the point are zeros that stay
+    if (last >= k) {
+      *o++ = '.';
+      for (int i = k; i <= last; ++i) *o++ = d[i];
+    }
+  } else {
+    *o++ = '0';
+    *o++ = '.';
+    for (int i = 0; i < -k; ++i) *o++ = '0';
+    for (int i = 0; i <= last; ++i) *o++ = d[i];
+  }
+  return (int)(o - out);
+}
+
 static inline int put_number(char* p, double v) {
+  if (const int n = put_fixed16(p, v)) return n;
   if (std::isnan(v)) {
     std::memcpy(p, "nan", 3);
     return 3;

@@ -429,7 +429,8 @@ def test_delaunay_points_reports_ties_and_rejects_what_qhull_must_decide():
 	g = np.stack(np.meshgrid(np.arange(12.0), np.arange(9.0)), axis=-1).reshape(-1, 2)
 	simplices, _, ties = _shim.delaunay_points(g)
 	assert len(simplices) == 2 * 11 * 8 and ties == 11 * 8  # every unit square is a tie
-	for bad in (g[:2], np.vstack([g, g[5:6]]), np.stack([np.arange(5.0), 2 * np.arange(5.0)], axis=-1)):
+	huge = np.array([[0.0, 0.0], [1e80, 0.0], [0.0, 1.0], [1.0, 1.0]])
+	for bad in (g[:2], np.vstack([g, g[5:6]]), np.stack([np.arange(5.0), 2 * np.arange(5.0)], axis=-1), huge, huge * 1e-150):
 		with pytest.raises(_shim.OgdError) as e:
 			_shim.delaunay_points(bad)
 		assert e.value.status == _shim.ERR_UNSUPPORTED
@@ -501,3 +502,23 @@ def test_ring_tables_equal_the_per_ring_functions():
 	assert valid.sum() > 10 and (~valid).sum() >= 8
 	assert finite.tolist() == [bool(np.all(np.isfinite(r))) for r in rings]
 	assert distinct.tolist() == [len(geometry.without_repeats(r)) for r in rings]
+
+
+def test_wkt_numbers_equal_printf_16g():
+	"""ogd_wkt_ring_text formats coordinates of page magnitude without printf (128-bit integer rounding of the exact
+	decimal expansion); every number must read as C's "%.16g" does, which is what GEOS' WKTWriter prints
+	(ref: origami/batch/detect/dewarp.py:39).  Python's % formatting is correctly rounded like glibc's."""
+	rng = np.random.default_rng(12)
+	x = np.arange(1, 50001, dtype=np.float64)
+	cases = np.concatenate([
+		rng.uniform(0, 8000, 200000), 10.0 ** rng.uniform(-7, 17, 200000) * rng.choice([-1, 1], 200000),
+		rng.integers(0, 8000, 50000) / 1024.0, np.round(rng.uniform(0, 8000, 50000), 3),
+		np.nextafter(x / 8, np.inf), np.nextafter(x / 8, -np.inf), x * 0.1, x / 3,
+		[0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1e-4, 9.999999999999999e-5, 1e15, 999999999999999.9, 999999999999999.94,
+			0.9999999999999999, 9.999999999999999e14, 123456789012345.6, 1e-5, 5e-324, 1.7976931348623157e308, 2.5,
+			0.00012345678901234567, 1234.5, 8075.0, 0.30000000000000004, np.inf, -np.inf]])
+	flat = cases.reshape(-1, 2)
+	text = _shim.wkt_ring_texts_table(flat, np.array([0, len(flat)], dtype=np.int64))[0]
+	got = text[1:-1].replace(",", "").split(" ")
+	want = ["%.16g" % v for v in cases]
+	assert got == want
