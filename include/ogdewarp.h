@@ -279,6 +279,19 @@ int ogd_wkt_parse(const char* text, const int64_t* text_offsets, int n, int8_t* 
  * adds up, ref: origami/batch/detect/dewarp.py:29-31): out[r] = sum_i (x_i - x_0) * (y_{i-1} - y_{i+1}) / 2. */
 int ogd_rings_area_signed(const double* pts, const int64_t* offsets, int nrings, double* out);
 
+/* ---- PNG page scans (host code) ------------------------------------------------------
+ * ref: origami/core/page.py:82-88 (PIL.Image.open: the page's pixels, decoded anew by every stage).
+ * A PNG's pixel data is one serial zlib stream; libogdewarp brings its own inflate (csrc/ogd_inflate.h: 64-bit
+ * bit buffer, 10-bit tables with literal pairs, several symbols per refill) because that loop, not the GPU, bounds a PNG page.
+ * ogd_png_info: size and channel count (1 grey, 3 RGB) of an 8-bit non-interlaced grey or RGB file;
+ * OGD_ERR_UNSUPPORTED for every other kind (palette, 16 bit, alpha, Adam7: the caller keeps PIL for those).
+ * ogd_png_decode_u8: the pixels, row y at out + y * out_stride, channels interleaved as PIL's "L" / "RGB" arrays. */
+int ogd_png_info(const uint8_t* file, int64_t n, int* width, int* height, int* channels);
+int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_stride);
+/* The zlib stream decoder on its own (what zlib.decompress does): n_out bytes written to out[cap];
+ * OGD_ERR_INVALID for corrupt, truncated or too long data (Adler-32 verified). */
+int ogd_inflate_zlib(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t cap, int64_t* n_out);
+
 /* ---- the march of the node grid on the device -------------------------------------
  * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),
  * :441-493 (grid_hv without the border extension), :176-263 (ShapelyBatchIntersections).

@@ -90,6 +90,9 @@ SIGNATURES = {
 	"ogd_delaunay_points": (c_int, [
 		c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p]),
 	"ogd_wkt_ring_text": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+	"ogd_png_info": (c_int, [c_void_p, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+	"ogd_png_decode_u8": (c_int, [c_void_p, c_int64, c_void_p, c_int64]),
+	"ogd_inflate_zlib": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
 	"ogd_wkt_parse": (c_int, [
 		c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
 		POINTER(c_int64)]),
@@ -703,4 +706,30 @@ def rings_area_signed(flat, offsets):
 	offsets = _c(offsets, np.int64)
 	out = np.zeros(len(offsets) - 1, dtype=np.float64)
 	check(load().ogd_rings_area_signed(_ptr(flat), _ptr(offsets), len(out), _ptr(out)))
+	return out
+
+
+def inflate_zlib(data, size):
+	"""zlib.decompress(data) for a stream whose decompressed size is known to be at most `size` (host code)."""
+	data = bytes(data)
+	out = np.empty(max(int(size), 1), dtype=np.uint8)
+	n = c_int64(0)
+	check(load().ogd_inflate_zlib(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), _ptr(out), int(size), ctypes.byref(n)))
+	return out[:n.value]
+
+
+def png_info(data):
+	"""(width, height, channels) of an 8-bit non-interlaced grey / RGB PNG; OgdError(ERR_UNSUPPORTED) for other kinds."""
+	data = bytes(data)
+	w, h, c = c_int(0), c_int(0), c_int(0)
+	check(load().ogd_png_info(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)))
+	return w.value, h.value, c.value
+
+
+def png_decode(data):
+	"""(H, W) or (H, W, 3) uint8 pixels of a PNG file's bytes, as np.array(PIL.Image.open(...)) gives them."""
+	data = bytes(data)
+	w, h, c = png_info(data)
+	out = np.empty((h, w) if c == 1 else (h, w, c), dtype=np.uint8)
+	check(load().ogd_png_decode_u8(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), _ptr(out), w * c))
 	return out
