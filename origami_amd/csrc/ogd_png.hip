@@ -8,7 +8,10 @@
 // (one checksum over the decoded bytes already answers "is this the image that was written").
 #include "ogd_common.h"
 #include "ogd_inflate.h"
+#include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 #include <thread>
@@ -42,70 +45,151 @@ int read_header(const uint8_t* file, int64_t n, PngHeader& h) {
   return OGD_OK;
 }
 
+// The Paeth predictor without branches (page noise makes its comparisons unpredictable): a = left, b = up,
+// c = up-left; the distances |p - a|, |p - b|, |p - c| of p = a + b - c are |b - c|, |a - c|, |a + b - 2c|.
 inline int paeth(int a, int b, int c) {
-  const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
-  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+  const int db = b - c, da = a - c;
+  int pa = db < 0 ? -db : db;
+  const int pb = da < 0 ? -da : da;
+  const int s = db + da;
+  const int pc = s < 0 ? -s : s;
+  int r = a;
+  r = pb < pa ? b : r;
+  pa = pb < pa ? pb : pa;
+  r = pc < pa ? c : r;
+  return r;
 }
 
-// One row: f = the filtered bytes behind the filter byte `type`, prev = the finished row above (zeros for row 0).
+// Bytes [b, e) of one row (b, e multiples of BPP or the row's end): f = the filtered bytes behind the filter byte
+// `type` (0 .. 4), prev = the finished row above (zeros for row 0).  carry (Average / Paeth, rows done in pieces):
+// the left and up-left pixel of position b on entry, of position e on return.
 template <int BPP>
-inline bool unfilter_row(int type, const uint8_t* f, const uint8_t* prev, uint8_t* o, int64_t rowbytes) {
+inline void unfilter_row(int type, const uint8_t* f, const uint8_t* prev, uint8_t* o, int64_t rowbytes, int64_t b, int64_t e,
+                         int* carry = nullptr) {
+  (void)rowbytes;
   switch (type) {
     case 0:
-      std::memcpy(o, f, (size_t)rowbytes);
-      return true;
-    case 1: {
+      std::memcpy(o + b, f + b, (size_t)(e - b));
+      return;
+    case 1: {  // whole rows only (no dependence on the row above)
       uint8_t acc[BPP];
       for (int c = 0; c < BPP; ++c) acc[c] = 0;
-      for (int64_t i = 0; i + BPP <= rowbytes; i += BPP)
+      for (int64_t i = b; i + BPP <= e; i += BPP)
         for (int c = 0; c < BPP; ++c) o[i + c] = acc[c] = (uint8_t)(acc[c] + f[i + c]);
-      return true;
+      return;
     }
     case 2:
-      for (int64_t i = 0; i < rowbytes; ++i) o[i] = (uint8_t)(f[i] + prev[i]);
-      return true;
-    case 3:
-      for (int64_t i = 0; i < BPP && i < rowbytes; ++i) o[i] = (uint8_t)(f[i] + (prev[i] >> 1));
-      for (int64_t i = BPP; i < rowbytes; ++i) o[i] = (uint8_t)(f[i] + ((o[i - BPP] + prev[i]) >> 1));
-      return true;
-    case 4:
-      for (int64_t i = 0; i < BPP && i < rowbytes; ++i) o[i] = (uint8_t)(f[i] + prev[i]);  // paeth(0, b, 0) = b
-      for (int64_t i = BPP; i < rowbytes; ++i) o[i] = (uint8_t)(f[i] + paeth(o[i - BPP], prev[i], prev[i - BPP]));
-      return true;
-    default:
-      return false;
+      for (int64_t i = b; i < e; ++i) o[i] = (uint8_t)(f[i] + prev[i]);
+      return;
+    // Average and Paeth feed every output byte into the next pixel: the running left (and up-left) values are kept in
+    // locals, so that the chain does not go through memory (o, prev and f may alias as far as the compiler knows)
+    case 3: {
+      int left[BPP];
+      for (int c = 0; c < BPP; ++c) left[c] = carry ? carry[c] : 0;
+      for (int64_t i = b; i + BPP <= e; i += BPP)
+        for (int c = 0; c < BPP; ++c) {
+          left[c] = (f[i + c] + ((left[c] + prev[i + c]) >> 1)) & 255;
+          o[i + c] = (uint8_t)left[c];
+        }
+      if (carry)
+        for (int c = 0; c < BPP; ++c) carry[c] = left[c];
+      return;
+    }
+    default: {
+      int left[BPP], upleft[BPP];
+      for (int c = 0; c < BPP; ++c) {
+        left[c] = carry ? carry[c] : 0;
+        upleft[c] = carry ? carry[BPP + c] : 0;
+      }
+      for (int64_t i = b; i + BPP <= e; i += BPP)
+        for (int c = 0; c < BPP; ++c) {
+          const int up = prev[i + c];
+          left[c] = (f[i + c] + paeth(left[c], up, upleft[c])) & 255;
+          upleft[c] = up;
+          o[i + c] = (uint8_t)left[c];
+        }
+      if (carry)
+        for (int c = 0; c < BPP; ++c) {
+          carry[c] = left[c];
+          carry[BPP + c] = upleft[c];
+        }
+      return;
+    }
   }
 }
 
-// The consumer of the inflate thread's output: rows are unfiltered (and summed for the Adler-32) as soon as the
-// decoder has published them.  raw: height rows of (filter byte + rowbytes); out: rows of rowbytes at out_stride.
-// Returns the row with an unknown filter type, or -1; stops early when `failed` is set.
+// Unfiltering behind the inflate thread, rows dealt round-robin to `nworkers` threads.  Up, Average and Paeth rows
+// need the finished row above, byte for byte, so a worker publishes how far its row has got (done[y], in chunks)
+// and the worker on the next row stays one chunk behind it: a skewed wavefront over the rows.  Dependencies only
+// point upwards and every worker takes its rows top to bottom, so nobody waits on a row that waits on him.
+// Scanned pages with correlated noise are mostly Paeth rows — a serial ~14-operation chain per byte that no
+// single thread gets through faster than the inflate thread delivers.
+struct UnfilterShared {
+  const uint8_t* raw;
+  int height;
+  int64_t rowbytes;
+  uint8_t* out;
+  int64_t out_stride;
+  const std::atomic<int64_t>* progress;  // bytes of raw that are final
+  const std::atomic<bool>* finished;     // the decoder has returned
+  std::atomic<int64_t>* done;            // [height] bytes of output row y that are final
+  std::atomic<int> bad_row{-1};          // first row with an unknown filter type (-2: the stream ended early)
+};
+
+// The followers are faster than the decoder and mostly wait for it; a block of the stream takes it ~50 us.  They
+// sleep instead of spinning: a worker process often has a CPU quota, and cycles burnt in a spin are the decoder's.
+inline void wait_for_decoder() { std::this_thread::sleep_for(std::chrono::microseconds(40)); }
+
+constexpr int64_t UNFILTER_CHUNK = 1020;  // whole pixels of 1, 2, 3 or 4 bytes
+
 template <int BPP>
-int unfilter_behind(const uint8_t* raw, int height, int64_t rowbytes, uint8_t* out, int64_t out_stride,
-                    const std::atomic<int64_t>& progress, const std::atomic<bool>& finished, uint32_t& adler) {
-  std::vector<uint8_t> zero((size_t)rowbytes, 0);
-  const uint8_t* prev = zero.data();
+void unfilter_worker(UnfilterShared& sh, int worker, int nworkers) {
+  std::vector<uint8_t> zero((size_t)sh.rowbytes, 0);
   int64_t ready = 0;
-  adler = 1;
-  for (int y = 0; y < height; ++y) {
-    const int64_t need = (int64_t)(y + 1) * (rowbytes + 1);
+  for (int y = worker; y < sh.height; y += nworkers) {
+    if (sh.bad_row.load(std::memory_order_relaxed) != -1) return;
+    const int64_t need = (int64_t)(y + 1) * (sh.rowbytes + 1);
     while (ready < need) {
-      ready = progress.load(std::memory_order_acquire);
+      ready = sh.progress->load(std::memory_order_acquire);
       if (ready >= need) break;
-      if (finished.load(std::memory_order_acquire)) {
-        ready = progress.load(std::memory_order_acquire);
-        if (ready < need) return -2;  // the stream ended early (the decoder reports why)
+      if (sh.finished->load(std::memory_order_acquire)) {
+        ready = sh.progress->load(std::memory_order_acquire);
+        if (ready < need) {
+          sh.bad_row.store(-2);
+          return;
+        }
         break;
       }
-      std::this_thread::yield();
+      wait_for_decoder();
     }
-    const uint8_t* f = raw + (int64_t)y * (rowbytes + 1);
-    adler = inflate::adler32(adler, f, rowbytes + 1);
-    uint8_t* o = out + (int64_t)y * out_stride;
-    if (!unfilter_row<BPP>(f[0], f + 1, prev, o, rowbytes)) return y;
-    prev = o;
+    const uint8_t* f = sh.raw + (int64_t)y * (sh.rowbytes + 1);
+    const int type = f[0];
+    ++f;
+    uint8_t* o = sh.out + (int64_t)y * sh.out_stride;
+    const uint8_t* prev = y ? sh.out + (int64_t)(y - 1) * sh.out_stride : zero.data();
+    if (type > 4) {
+      sh.bad_row.store(y);
+      // rows below wait for this one: let them through, the result is discarded anyway
+      sh.done[y].store(sh.rowbytes, std::memory_order_release);
+      return;
+    }
+    if (type < 2 || y == 0) {  // None / Sub, or nothing above: the whole row at once
+      unfilter_row<BPP>(type, f, prev, o, sh.rowbytes, 0, sh.rowbytes);
+      sh.done[y].store(sh.rowbytes, std::memory_order_release);
+      continue;
+    }
+    int carry[2 * BPP];  // left / up-left of the chunk boundary
+    for (int c = 0; c < 2 * BPP; ++c) carry[c] = 0;
+    for (int64_t b = 0; b < sh.rowbytes; b += UNFILTER_CHUNK) {
+      const int64_t e = std::min(sh.rowbytes, b + UNFILTER_CHUNK);
+      while (sh.done[y - 1].load(std::memory_order_acquire) < e) {
+        if (sh.bad_row.load(std::memory_order_relaxed) != -1) return;
+        std::this_thread::yield();
+      }
+      unfilter_row<BPP>(type, f, prev, o, sh.rowbytes, b, e, carry);
+      sh.done[y].store(e, std::memory_order_release);
+    }
   }
-  return -1;
 }
 
 }  // namespace
@@ -161,20 +245,47 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
   const int64_t raw_bytes = (rowbytes + 1) * h.height;
   std::unique_ptr<uint8_t[]> raw(new (std::nothrow) uint8_t[(size_t)raw_bytes + 8]);  // not zeroed: 48 MB per page
   if (!raw) return fail(OGD_ERR_NOMEM, "out of host memory");
-  // the stream is decoded on a second thread; this one follows it row by row (Adler-32 + unfiltering)
+  // the stream is decoded on one thread, two more unfilter the rows behind it, this one sums the Adler-32
   int64_t got = 0;
   uint32_t stored = 0, summed = 1;
   std::atomic<int64_t> progress{0};
   std::atomic<bool> finished{false};
   int st = inflate::OK;
+  std::unique_ptr<std::atomic<int64_t>[]> done(new (std::nothrow) std::atomic<int64_t>[(size_t)h.height]);
+  if (!done) return fail(OGD_ERR_NOMEM, "out of host memory");
+  for (int y = 0; y < h.height; ++y) done[y].store(0, std::memory_order_relaxed);
+  UnfilterShared sh;
+  sh.raw = raw.get();
+  sh.height = h.height;
+  sh.rowbytes = rowbytes;
+  sh.out = out;
+  sh.out_stride = out_stride;
+  sh.progress = &progress;
+  sh.finished = &finished;
+  sh.done = done.get();
   std::thread decoder([&]() {
     st = inflate::inflate_zlib(z.data(), (int64_t)z.size(), raw.get(), raw_bytes, &got, false, &stored, &progress);
     finished.store(true, std::memory_order_release);
   });
-  const int bad_row = h.channels == 1
-      ? unfilter_behind<1>(raw.get(), h.height, rowbytes, out, out_stride, progress, finished, summed)
-      : unfilter_behind<3>(raw.get(), h.height, rowbytes, out, out_stride, progress, finished, summed);
+  constexpr int NW = 2;
+  std::thread workers[NW];
+  for (int k = 0; k < NW; ++k)
+    workers[k] = h.channels == 1 ? std::thread(unfilter_worker<1>, std::ref(sh), k, NW)
+                                 : std::thread(unfilter_worker<3>, std::ref(sh), k, NW);
+  for (int64_t at = 0; at < raw_bytes;) {  // Adler-32 of the filtered rows, as far as they are final
+    const int64_t ready = progress.load(std::memory_order_acquire);
+    if (ready > at) {
+      summed = inflate::adler32(summed, raw.get() + at, ready - at);
+      at = ready;
+    } else if (finished.load(std::memory_order_acquire)) {
+      if (progress.load(std::memory_order_acquire) <= at) break;
+    } else {
+      wait_for_decoder();
+    }
+  }
   decoder.join();
+  for (auto& w : workers) w.join();
+  const int bad_row = sh.bad_row.load();
   if (st != inflate::OK || got != raw_bytes)
     return fail(OGD_ERR_INVALID, "PNG: image data %s", st == inflate::OUTPUT_FULL ? "longer than the header says"
                                                        : st == inflate::TRUNCATED ? "truncated"
