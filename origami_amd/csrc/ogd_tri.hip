@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256) void tri_eval_ragged_kernel(TriView inner, int
 // every lattice point tests the staged records of its own cell in list order — the order tri_locate uses, so the rasteriser is
 // bit-identical to point queries.  Points the inner triangulation leaves open take a second pass over
 // the extrapolation triangulation.
-constexpr int RS_TW = 64, RS_TH = 16, RS_THREADS = 256, RS_PX = RS_TH / (RS_THREADS / RS_TW), RS_CAP = 160;
+#ifndef OGD_RS_TH
+#define OGD_RS_TH 16
+#endif
+constexpr int RS_TW = 64, RS_TH = OGD_RS_TH, RS_THREADS = 256, RS_PX = RS_TH / (RS_THREADS / RS_TW), RS_CAP = 160;
 
 __device__ __forceinline__ void cell_xy(const TriView& t, double x, double y, int& cx, int& cy) {
   cx = min(max((int)floor((x - t.gx0) * t.inv_cw), 0), t.gnx - 1);  // as cell_of, without the division to split it
