@@ -386,10 +386,16 @@ class Grid:
 class Dewarper:
 	"""ref: dewarp.py:579-627."""
 
-	def __init__(self, im, grid):
+	def __init__(self, im, grid, pixels=None):
+		"""pixels: the (H, W) uint8 array `im` was made from, if the caller still holds it (origami_amd.page.Page
+		after decoding a scan itself): spares the 48 MB copy PIL makes on the way back to numpy."""
 		self._im = im
 		self._grid = grid
 		self._dewarped = None
+		self._pixels = pixels
+
+	def _array(self):
+		return self._pixels if self._pixels is not None else np.asarray(self._im)
 
 	@property
 	def grid(self):
@@ -399,7 +405,7 @@ class Dewarper:
 	def dewarped(self):
 		if self._dewarped is None:
 			self._dewarped = PIL.Image.fromarray(_shim.dewarp_u8(
-				np.array(self._im), self._grid.points("sample"), self._grid.resolution,
+				self._array(), self._grid.points("sample"), self._grid.resolution,
 				interpolation=INTER_LINEAR))
 		return self._dewarped
 
@@ -410,7 +416,7 @@ class Dewarper:
 		if self._im.mode != "L":
 			raise ValueError("dewarped_jpeg needs an 'L' page, got mode %s" % self._im.mode)
 		return _shim.dewarp_jpeg_gray(
-			np.array(self._im), self._grid.points("sample"), self._grid.resolution, quality=quality)
+			self._array(), self._grid.points("sample"), self._grid.resolution, quality=quality)
 
 	def dewarp_image(self, im, interpolation=INTER_LINEAR):
 		"""Remap an image of any size (label map, RGB page) through the page's grid, scaled by

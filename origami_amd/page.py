@@ -43,6 +43,7 @@ class Page:
 		# first use: 0.19 s per broadsheet PNG that this stage never spends.
 		self._opened = PIL.Image.open(str(path))
 		self._warped = None
+		self._pixels = None  # the array self._warped was made from, when this class decoded the scan itself
 		self._device_page = None
 		self._grid = dewarping_transform
 		self._dewarper = None
@@ -62,7 +63,10 @@ class Page:
 			return None
 		data = Path(self._opened.filename).read_bytes()
 		pixels = _shim.jpeg_decode_gray(data)
-		return None if pixels is None else PIL.Image.fromarray(pixels)
+		if pixels is None:
+			return None
+		self._pixels = pixels
+		return PIL.Image.fromarray(pixels)
 
 	def _decode_png(self):
 		"""An 8-bit grey or RGB PNG without interlacing goes through libogdewarp's own inflate (ogd_png_decode_u8,
@@ -76,7 +80,10 @@ class Page:
 		except _shim.OgdError:
 			return None
 		im = PIL.Image.fromarray(pixels)
-		return im if im.mode == "L" else im.convert("L")
+		if im.mode != "L":
+			return im.convert("L")
+		self._pixels = pixels
+		return im
 
 	@property
 	def dewarped(self):
@@ -116,7 +123,7 @@ class Page:
 	@property
 	def dewarper(self):
 		if self._dewarper is None and self._grid is not None:
-			self._dewarper = Dewarper(self.warped, self._grid)
+			self._dewarper = Dewarper(self.warped, self._grid, pixels=self._pixels)
 		return self._dewarper
 
 	@property
@@ -126,5 +133,6 @@ class Page:
 			if self._warped is None and self._on_device_format():  # an undecoded JPEG scan never visits the host
 				self._device_page = _shim.DevicePage.from_jpeg(Path(self._opened.filename).read_bytes())
 			if self._device_page is None:
-				self._device_page = _shim.DevicePage(np.array(self.warped))
+				warped = self.warped
+				self._device_page = _shim.DevicePage(self._pixels if self._pixels is not None else np.asarray(warped))
 		return self._device_page
