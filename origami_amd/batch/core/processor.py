@@ -9,7 +9,6 @@ HIP call, and lets the workers pull chunks from one host-side queue: pages are i
 no collective and nothing crosses xGMI.
 """
 
-import functools
 import json
 import logging
 import multiprocessing
@@ -29,9 +28,9 @@ from .mutex import DatabaseMutex, DummyMutex, FileMutex
 IMAGE_SUFFIXES = (".jpg", ".png", ".tif", ".tiff")
 
 
-def chunks(items, n):
-	for i in range(0, len(items), n):
-		yield items[i:i + n]
+def chunks(items, size):
+	"""Consecutive slices of at most `size` items."""
+	return (items[at:at + size] for at in range(0, len(items), size))
 
 
 def _worker_main(processor_cls, options, data_path, rank, device, task_q, done_q):
@@ -67,84 +66,76 @@ def _worker_main(processor_cls, options, data_path, rank, device, task_q, done_q
 		done_q.put((rank, None, None))
 
 
+# The stage CLI every Processor shares: option names, types and defaults are the reference's (processor.py:276-347),
+# so that existing command lines keep working; --gpus and --devices are this build's additions.
+_CLI = (
+	("--processes", dict(type=int, default=1, help="Worker processes (CPU-side parallelism).")),
+	("--alive", dict(type=int, default=600, help="Seconds without progress after which the workers are stopped.")),
+	("--name", dict(type=str, default="", help="Regular expression a page path must match to be processed.")),
+	("--lock-strategy", dict(
+		type=click.Choice(["FILE", "DB", "NONE"], case_sensitive=False), default="DB",
+		help="Where page locks live: lock files, a SQLite database, or nowhere.")),
+	("--lock-level", dict(
+		type=click.Choice(["PAGE", "TASK"], case_sensitive=False), default="PAGE",
+		help="What a lock covers: the page, or this stage on the page.")),
+	("--lock-database", dict(type=click.Path(), required=False, help="Path of the lock database (DB strategy).")),
+	("--lock-timeout", dict(type=int, default=60, required=False, help="Seconds to wait for a lock (raise on NFS).")),
+	("--max-lock-age", dict(type=int, default=600, required=False, help="Locks older than this many seconds are stale.")),
+	("--overwrite", dict(is_flag=True, default=False, help="Redo pages whose results exist.")),
+	("--profile", dict(is_flag=True, default=False, help="(accepted for compatibility; not supported)")),
+	("--plain", dict(is_flag=True, default=False, help="One line per finished page, for pipes.")),
+	("--debug-write", dict(is_flag=True, default=False, help="(accepted for compatibility; not supported)")),
+	("--track-changes", dict(type=str, default="", help="(accepted for compatibility; not supported)")),
+	("--gpus", dict(type=int, default=0, help="Worker processes, one per GPU (0: work in this process).")),
+	("--devices", dict(type=str, default="", help="Comma separated GPU indices to use (default: all visible).")),
+)
+
+_LOCK_ACTORS = dict(PAGE=lambda processor: "page", TASK=lambda processor: processor.processor_name)
+
+
 class Processor:
 	def __init__(self, options):
 		self._options = dict(options)
-		self._overwrite = options.get("overwrite", False)
-		self._processes = options.get("processes", 1)
-		self._timeout = options.get("alive", 600)
-		self._name = options.get("name", "")
+		get = self._options.get
+		self._overwrite = bool(get("overwrite", False))
+		self._processes = get("processes", 1)
+		self._timeout = get("alive", 600)
+		self._name = get("name", "")
 		self._verbose = False
+		self._plain = get("plain")
+		self._print_paths = bool(self._plain)
 
-		self._lock_strategy = (options.get("lock_strategy") or "DB").upper()
-		self._lock_level = (options.get("lock_level") or "PAGE").upper()
-		self._lock_timeout = options.get("lock_timeout", 60)
-		self._max_lock_age = options.get("max_lock_age")
-		self._lock_chunk_size = 25
-		self._lock_database = options.get("lock_database")
+		self._lock_strategy = (get("lock_strategy") or "DB").upper()
+		self._lock_level = (get("lock_level") or "PAGE").upper()
+		self._lock_timeout = get("lock_timeout", 60)
+		self._max_lock_age = get("max_lock_age")
+		self._lock_database = get("lock_database")
+		self._lock_chunk_size = 25  # pages locked (and handed to a worker) together, ref: processor.py:451-453
 		self._mutex = None
 		if self._lock_strategy not in ("DB", "FILE", "NONE"):
 			raise ValueError(self._lock_strategy)
+		if self._lock_level not in _LOCK_ACTORS:
+			raise ValueError(self._lock_level)
 
-		self._gpus = options.get("gpus", 0) or 0
-		self._devices = options.get("devices") or ""
+		self._gpus = get("gpus", 0) or 0
+		self._devices = get("devices") or ""
 		self._rank = 0
 		self._device = None
-
-		self._plain = options.get("plain")
-		self._print_paths = bool(self._plain)
-		if options.get("profile") or options.get("track_changes") or options.get("debug_write"):
+		if get("profile") or get("track_changes") or get("debug_write"):
 			logging.warning("--profile, --track-changes and --debug-write are not supported by this build.")
 
 	@staticmethod
-	def options(f):
-		options = [
-			click.option('--processes', type=int, default=1, help="Number of parallel processes to employ."),
-			click.option('--alive', type=int, default=600, help="Seconds to wait after inactive process is killed."),
-			click.option('--name', type=str, default="", help="Only process paths that conform to the given pattern."),
-			click.option(
-				'--lock-strategy', type=click.Choice(['FILE', 'DB', 'NONE'], case_sensitive=False), default="DB",
-				help="How to implement locking for concurrency."),
-			click.option(
-				'--lock-level', type=click.Choice(['PAGE', 'TASK'], case_sensitive=False), default="PAGE",
-				help="Lock granularity."),
-			click.option(
-				'--lock-database', type=click.Path(), required=False,
-				help="Mutex database path used for concurrent processing"),
-			click.option(
-				'--lock-timeout', type=int, default=60, required=False,
-				help="Seconds to wait to acquire locking. NFS volumes might need high values."),
-			click.option(
-				'--max-lock-age', type=int, default=600, required=False,
-				help="Maximum age of a lock in seconds until it is considered invalid."),
-			click.option('--overwrite', is_flag=True, default=False, help="Recompute and overwrite existing result files."),
-			click.option('--profile', is_flag=True, default=False, help="Enable profiling and show results."),
-			click.option('--plain', is_flag=True, default=False, help="Print plain output that is friendly to piping."),
-			click.option('--debug-write', is_flag=True, default=False, help="Debug which files are written."),
-			click.option('--track-changes', type=str, default="", help="Recompute files and track changes with given tag."),
-			# additive (MI355X build)
-			click.option('--gpus', type=int, default=0, help="Worker processes, one per GPU (0: work in this process)."),
-			click.option('--devices', type=str, default="", help="Comma separated GPU indices to use (default: all visible)."),
-		]
-		return functools.reduce(lambda x, opt: opt(x), options, f)
+	def options(command):
+		"""Decorator that hangs the shared options on a click command."""
+		for flag, spec in reversed(_CLI):
+			command = click.option(flag, **spec)(command)
+		return command
+
+	# ---- what a stage provides -------------------------------------------------------------------------
 
 	@property
 	def processor_name(self):
-		return self.__class__.__name__
-
-	def is_image(self, path):
-		if path.suffix.lower() in IMAGE_SUFFIXES:
-			return True
-		try:
-			import PIL.Image
-			with PIL.Image.open(str(path)) as im:
-				im.verify()
-			return True
-		except Exception:
-			return False
-
-	def should_process(self, page_path):
-		return True
+		return type(self).__name__
 
 	def artifacts(self):
 		raise NotImplementedError()
@@ -152,129 +143,141 @@ class Processor:
 	def process(self, page_path, **kwargs):
 		raise NotImplementedError()
 
+	def should_process(self, page_path):
+		return True
+
+	def is_image(self, path):
+		if path.suffix.lower() in IMAGE_SUFFIXES:
+			return True
+		import PIL.Image
+		try:
+			with PIL.Image.open(str(path)) as im:
+				im.verify()
+		except Exception:
+			return False
+		return True
+
 	def lock_or_open(self, path, mode):
 		return open(path, mode)
 
-	def prepare_process(self, page_path):
-		file_writer = AtomicFileWriter(overwrite=self._overwrite)
-		kwargs = dict()
-		for arg, spec in self.artifacts():
-			f = spec.instantiate(page_path=page_path, processor=self, file_writer=file_writer)
-			f.fix_inconsistent()
-			if not f.is_ready():
-				if self._verbose:
-					print("skipping %s: missing %s" % (page_path, f.missing))
-				return False
-			kwargs[arg] = f
-		return kwargs
+	# ---- one page ---------------------------------------------------------------------------------------
 
-	def _trigger_process1(self, p, kwargs, locked):
-		work = locked
-		if not locked:
-			logging.warning("failed to obtain lock for %s. ignoring." % p)
+	def prepare_process(self, page_path):
+		"""The page's readers and writers by argument name, or False if an input is missing or the outputs exist
+		(ref: processor.py:381-393)."""
+		writer = AtomicFileWriter(overwrite=self._overwrite)
+		files = {}
+		for arg, spec in self.artifacts():
+			handle = spec.instantiate(page_path=page_path, processor=self, file_writer=writer)
+			handle.fix_inconsistent()
+			if not handle.is_ready():
+				if self._verbose:
+					print("skipping %s: missing %s" % (page_path, handle.missing))
+				return False
+			files[arg] = handle
+		return files
+
+	def _run_page(self, page, files, locked):
+		"""process() for one page under its lock, with the outcome recorded in the page's runtime.json
+		(ref: processor.py:395-423: COMPLETED with the elapsed time, or FAILED with the traceback)."""
 		try:
-			if work:
-				# a concurrent worker might already have done this.
-				work = all(f.is_ready() for f in kwargs.values())
-			if work:
-				t0 = time.perf_counter()
-				find_data_path(p).mkdir(exist_ok=True)
-				runtime_info = self.process(p, **kwargs)
-				if runtime_info is None:
-					runtime_info = dict()
-				runtime_info["status"] = "COMPLETED"
-				runtime_info["elapsed"] = round(time.perf_counter() - t0, 2)
-				if self._device is not None:
-					runtime_info["device"] = self._device
-				self._update_runtime_info(p, {self.processor_name: runtime_info})
+			if not locked:
+				logging.warning("failed to obtain lock for %s. ignoring." % page)
+				return
+			if not all(f.is_ready() for f in files.values()):
+				return  # another worker did this page between queueing and locking
+			started = time.perf_counter()
+			find_data_path(page).mkdir(exist_ok=True)
+			record = self.process(page, **files) or {}
+			record["status"] = "COMPLETED"
+			record["elapsed"] = round(time.perf_counter() - started, 2)
+			if self._device is not None:
+				record["device"] = self._device
+			self._update_runtime_info(page, {self.processor_name: record})
 		except KeyboardInterrupt:
-			logging.exception("Interrupted at %s." % p)
+			logging.exception("Interrupted at %s." % page)
 			raise
 		except Exception:
-			logging.exception("Failed to process %s." % p)
-			self._update_runtime_info(p, {
-				self.processor_name: dict(status="FAILED", traceback=traceback.format_exc())})
+			logging.exception("Failed to process %s." % page)
+			self._update_runtime_info(page, {self.processor_name: dict(status="FAILED", traceback=traceback.format_exc())})
 		finally:
-			kwargs.clear()
+			files.clear()
 
 	def _trigger_process(self, chunk):
+		"""Runs the (index, page, files) items of a chunk under their locks; yields (index, page) as each is over."""
 		if not chunk:
 			return
-		if self._lock_level == "PAGE":
-			actor = "page"
-		elif self._lock_level == "TASK":
-			actor = self.processor_name
-		else:
-			raise ValueError(self._lock_level)
-		if isinstance(self._mutex, FileMutex):
-			groups = [[item] for item in chunk]
-		else:
-			groups = [chunk]
+		actor = _LOCK_ACTORS[self._lock_level](self)
+		# lock files are taken page by page, database locks for the chunk in one transaction
+		groups = [[item] for item in chunk] if isinstance(self._mutex, FileMutex) else [chunk]
 		for group in groups:
-			with self._mutex.lock(actor, [str(p) for _, p, _ in group]) as locked:
-				for i, p, kwargs in group:
-					self._trigger_process1(p, kwargs, locked)
-					yield i, p
+			with self._mutex.lock(actor, [str(page) for _, page, _ in group]) as locked:
+				for index, page, files in group:
+					self._run_page(page, files, locked)
+					yield index, page
 
 	# ---- queue ---------------------------------------------------------------------------------------
 
+	@staticmethod
+	def _listed_pages(listing):
+		"""Paths named one per line in a text file."""
+		with open(listing, "r") as f:
+			for line in f:
+				if line.strip():
+					page = Path(line.strip())
+					if page.exists():
+						yield page
+					else:
+						print("skipping %s: path does not exist." % page)
+
+	@staticmethod
+	def _pages_below(root):
+		"""Files of a directory tree in sorted order; `<page>.out` folders hold results, not pages."""
+		for folder, dirs, names in os.walk(root):
+			if folder.endswith(".out"):
+				dirs.clear()
+				continue
+			dirs.sort()
+			for name in sorted(names):
+				yield Path(folder) / name
+
 	def _build_queue(self, path):
-		path = Path(path)
-		if not path.exists():
-			raise FileNotFoundError("%s does not exist." % path)
-		queued = []
-		counts = dict(images=0)
-
-		def add_path(p):
-			if not p.exists():
-				print("skipping %s: path does not exist." % p)
-				return
-			if self._name and not re.search(self._name, str(p)):
-				return
-			if not self.is_image(p):
-				return
-			counts['images'] += 1
-			if not self.should_process(p):
-				return
-			kwargs = self.prepare_process(p)
-			if kwargs is not False:
-				queued.append((len(queued), p, kwargs))
-
-		if not path.is_dir():
-			if path.suffix == ".txt":
-				with open(path, "r") as f:
-					for line in f:
-						line = line.strip()
-						if line:
-							add_path(Path(line))
-			else:
-				raise FileNotFoundError("%s is not a valid path or text file of paths." % path)
-		else:
-			print(f"scanning {path}... ", flush=True, end="")
-			for folder, dirs, filenames in os.walk(path):
-				folder = Path(folder)
-				if folder.name.endswith(".out"):
-					dirs.clear()
-					continue
-				dirs.sort()
-				for filename in sorted(filenames):
-					add_path(folder / filename)
+		"""[(index, page path, readers / writers)] of the pages that are ready for this stage
+		(ref: processor.py:425-474: same walk order, filters and messages)."""
+		root = Path(path)
+		if not root.exists():
+			raise FileNotFoundError("%s does not exist." % root)
+		tree = root.is_dir()
+		if not tree and root.suffix != ".txt":
+			raise FileNotFoundError("%s is not a valid path or text file of paths." % root)
+		if tree:
+			print(f"scanning {root}... ", flush=True, end="")
+		n_images, queued = 0, []
+		for page in (self._pages_below(root) if tree else self._listed_pages(root)):
+			if self._name and not re.search(self._name, str(page)):
+				continue
+			if not self.is_image(page):
+				continue
+			n_images += 1
+			if not self.should_process(page):
+				continue
+			files = self.prepare_process(page)
+			if files is not False:
+				queued.append((len(queued), page, files))
+		if tree:
 			print("done.", flush=True)
-			print(f"{counts['images']} documents found, {len(queued)} ready to process.")
+			print(f"{n_images} documents found, {len(queued)} ready to process.")
 		return queued
 
 	def _make_mutex(self, path):
-		if self._lock_strategy == "DB":
-			if self._lock_database:
-				db_path = Path(self._lock_database)
-			elif Path(path).is_dir():
-				db_path = Path(path) / "origami.lock.db"
-			else:
-				db_path = Path(path).parent / "origami.lock.db"
-			return DatabaseMutex(db_path, timeout=self._lock_timeout)
-		elif self._lock_strategy == "FILE":
+		if self._lock_strategy == "FILE":
 			return FileMutex()
-		return DummyMutex()
+		if self._lock_strategy == "NONE":
+			return DummyMutex()
+		where = Path(path)
+		database = Path(self._lock_database) if self._lock_database else (
+			where if where.is_dir() else where.parent) / "origami.lock.db"
+		return DatabaseMutex(database, timeout=self._lock_timeout)
 
 	def worker_devices(self, n_workers):
 		"""GPU index of every worker: worker r -> devices[r % len(devices)]."""
@@ -370,26 +373,20 @@ class Processor:
 
 	# ---- runtime.json --------------------------------------------------------------------------------
 
-	def _update_json(self, page_path, artifact, updates):
+	def _update_runtime_info(self, page_path, updates):
+		"""Merges `updates` ({stage name: record}, None deletes) into the page's runtime.json; the file is replaced in
+		one step so that readers never see half of it (ref: processor.py:349-379).  Failures are logged, not raised:
+		bookkeeping must not fail a page that was processed."""
 		try:
-			json_path = find_data_path(page_path) / artifact.filename()
-			new_json_path = json_path.parent / (json_path.stem + ".updated" + json_path.suffix)
-			if new_json_path.exists():
-				os.remove(new_json_path)
-			data = dict()
-			if json_path.exists():
-				with open(json_path, "r") as f:
-					data = json.loads(f.read())
-			for k, v in updates.items():
-				if v is None:
-					del data[k]
+			target = find_data_path(page_path) / Artifact.RUNTIME.filename()
+			merged = json.loads(target.read_text()) if target.exists() else {}
+			for key, value in updates.items():
+				if value is None:
+					merged.pop(key)
 				else:
-					data[k] = v
-			with open(new_json_path, "w") as f:
-				json.dump(data, f)
-			os.replace(new_json_path, json_path)
+					merged[key] = value
+			scratch = target.with_name(target.stem + ".updated" + target.suffix)
+			scratch.write_text(json.dumps(merged))
+			os.replace(scratch, target)
 		except Exception:
 			logging.error(traceback.format_exc())
-
-	def _update_runtime_info(self, page_path, updates):
-		self._update_json(page_path, Artifact.RUNTIME, updates)
