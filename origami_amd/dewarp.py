@@ -55,56 +55,44 @@ class Geometry:
 
 class Samples:
 	"""Flow samples (x, y, phi) of one direction; `flow.zip` members <name>.npy / <name>.json
-	(ref: dewarp.py:34-105, docs/formats.md:145-187)."""
+	(ref: dewarp.py:34-105, docs/formats.md:145-187: a float64 (n, 3) table, or shape (3, 0) when there are none,
+	beside {"version": 1, "size": [W, H]})."""
 
-	def __init__(self, geometry):
-		self._points = []
-		self._values = []
+	def __init__(self, geometry, points=(), values=()):
 		self._geometry = geometry
+		self._points = list(points)
+		self._values = list(values)
+
+	@classmethod
+	def open(cls, zf, name):
+		size = json.loads(zf.read(name + ".json"))["size"]
+		table = np.load(io.BytesIO(zf.read(name + ".npy")), allow_pickle=False)
+		if table.size:
+			return cls(Geometry(*size), table[:, :2], table[:, 2])
+		none = cls(Geometry(*size))
+		none._points = np.empty((2, 0))  # what the reference leaves in `points` for an empty member
+		return none
+
+	def save(self, zf, name):
+		if len(self._values):
+			xy = np.asarray(self._points, dtype=np.float64).reshape(-1, 2)
+			table = np.column_stack([xy, np.asarray(self._values, dtype=np.float64)])
+		else:
+			table = np.empty((3, 0), dtype=np.float64)
+		member = io.BytesIO()
+		np.save(member, table, allow_pickle=False)
+		zf.writestr(name + ".npy", member.getvalue())
+		zf.writestr(name + ".json", json.dumps(dict(version=1, size=self._geometry.size)))
 
 	def __len__(self):
 		return len(self._points)
 
-	@staticmethod
-	def open(zf, name):
-		info = json.loads(zf.read("%s.json" % name))
-		array = np.load(io.BytesIO(zf.read("%s.npy" % name)), allow_pickle=False)
-		samples = Samples(Geometry(*info["size"]))
-		if array.size > 0:
-			samples._points = list(array[:, :2])
-			samples._values = list(array[:, 2])
-		else:
-			samples._points = np.empty((2, 0))
-			samples._values = []
-		return samples
-
-	def save(self, zf, name):
-		points = np.array(self._points)
-		values = np.array(self._values)
-		if points.size == 0:
-			array = np.empty((3, 0))
-		else:
-			array = np.hstack([points, values[:, np.newaxis]])
-		data = io.BytesIO()
-		np.save(data, array.astype(np.float64), allow_pickle=False)
-		zf.writestr("%s.npy" % name, data.getvalue())
-		zf.writestr("%s.json" % name, json.dumps(dict(version=1, size=self._geometry.size)))
-
-	@property
-	def geometry(self):
-		return self._geometry
-
-	@property
-	def points(self):
-		return self._points
-
-	@property
-	def values(self):
-		return self._values
+	geometry = property(lambda self: self._geometry)
+	points = property(lambda self: self._points)
+	values = property(lambda self: self._values)
 
 	def append(self, point, value):
-		self._points.append(point)
-		self._values.append(value)
+		self.extend([point], [value])
 
 	def extend(self, points, values):
 		self._points.extend(points)
@@ -139,17 +127,18 @@ class Field:
 		return np.squeeze(np.dstack([dx, dy]), axis=0)
 
 	def estimate_extent(self, axis, limit, step_size):
-		starts = range(0, self._size[1 - axis], step_size)
+		"""Euler steps of `step_size` until every walk started along the other axis has passed `limit`, plus one
+		(ref: dewarp.py:124-140).  The stage asks ogd_march_shape for both axes in one launch; this host form is
+		the reference's method, kept for its callers."""
+		starts = np.arange(0, self._size[1 - axis], step_size)
 		pts = np.zeros((len(starts), 2), dtype=np.float32)
 		pts[:, 1 - axis] = starts
-		n_steps = 1
-		max_steps = 2 * (1 + self._size[axis])
-		while np.any(pts[:, axis] < limit) and n_steps < max_steps:
+		bound = 2 * (1 + self._size[axis])
+		for n_steps in range(1, bound):
+			if not np.any(pts[:, axis] < limit):
+				return n_steps
 			pts += self.get(pts) * step_size
-			n_steps += 1
-		if n_steps >= max_steps:
-			raise RuntimeError("n_steps exceeded %d" % max_steps)
-		return n_steps
+		raise RuntimeError("n_steps exceeded %d" % bound)
 
 
 class Transformer:
@@ -344,20 +333,22 @@ class Grid:
 
 	@staticmethod
 	def open(path):
+		"""dewarp.zip: data.npy (float32 node positions) + meta.json {"version", "cell", "shape"}
+		(ref: dewarp.py:537-553, docs/formats.md:272-306)."""
 		with zipfile.ZipFile(path, "r") as zf:
-			info = json.loads(zf.read("meta.json").decode("utf8"))
-			grid = np.load(io.BytesIO(zf.read("data.npy")), allow_pickle=False)
-		return Grid(grid.reshape(info["shape"]), info["cell"])
+			meta = json.loads(zf.read("meta.json"))
+			nodes = np.load(io.BytesIO(zf.read("data.npy")), allow_pickle=False)
+		return Grid(nodes.reshape(meta["shape"]), meta["cell"])
 
 	def save(self, path, compression=zipfile.ZIP_DEFLATED):
-		data = io.BytesIO()
-		np.save(data, self._grid_hv.astype(np.float32), allow_pickle=False)
-		info = dict(version=1, cell=self._grid_res, shape=self._grid_hv.shape)
+		member = io.BytesIO()
+		np.save(member, np.asarray(self._grid_hv, dtype=np.float32), allow_pickle=False)
+		meta = dict(version=1, cell=self._grid_res, shape=self._grid_hv.shape)
 		# deflate level 1: float32 node positions barely shrink at any level (85 %), the default level only
 		# costs more time; method (deflate), member names, order and contents are the reference's
 		with zipfile.ZipFile(path, "w", compression, compresslevel=1) as zf:
-			zf.writestr("data.npy", data.getvalue())
-			zf.writestr("meta.json", json.dumps(info))
+			zf.writestr("data.npy", member.getvalue())
+			zf.writestr("meta.json", json.dumps(meta))
 
 	@property
 	def transformer(self):
