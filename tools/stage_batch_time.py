@@ -23,6 +23,8 @@ def main():
 	n_poly = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 	W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6000, 8000)
 	worker_counts = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
+	if max(worker_counts) > 15:  # the GPU boxes allow 16 processes on a GPU at once, and this one is one of them
+		raise SystemExit("at most 15 workers")
 	workers = worker_counts[0]
 
 	_shim.init(0)
