@@ -292,6 +292,18 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
  * OGD_ERR_INVALID for corrupt, truncated or too long data (Adler-32 verified). */
 int ogd_inflate_zlib(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t cap, int64_t* n_out);
 
+/* ---- the stage's output archives (host code) -------------------------------------------
+ * ref: origami/batch/core/io.py:516-518, 565-577 (contours.N.zip), origami/core/dewarp.py:545-553 (dewarp.zip): members
+ * written with zipfile.ZIP_DEFLATED.  ogd_deflate_raw writes a raw deflate stream (what a zip member of method 8
+ * holds) of dynamic-Huffman literal blocks, or stored blocks where those would be larger: no string matching, which
+ * finds next to nothing in float32 node positions and coordinate text, at ~10x zlib's level-1 speed and within a few
+ * per cent of its size.  cap >= n + n / 1000 + 64 is always enough.
+ * ogd_deflate_many: members k = in[offsets[k] .. offsets[k+1]) -> out[out_offsets[k] .. out_offsets[k+1]) and their
+ * CRC-32s, one call per archive. */
+int ogd_deflate_raw(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out);
+int ogd_deflate_many(const uint8_t* in, const int64_t* offsets, int n, uint8_t* out, int64_t cap,
+                     int64_t* out_offsets, uint32_t* crcs);
+
 /* ---- the march of the node grid on the device -------------------------------------
  * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),
  * :441-493 (grid_hv without the border extension), :176-263 (ShapelyBatchIntersections).

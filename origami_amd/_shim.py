@@ -93,6 +93,8 @@ SIGNATURES = {
 	"ogd_png_info": (c_int, [c_void_p, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 	"ogd_png_decode_u8": (c_int, [c_void_p, c_int64, c_void_p, c_int64]),
 	"ogd_inflate_zlib": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
+	"ogd_deflate_raw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
+	"ogd_deflate_many": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
 	"ogd_wkt_parse": (c_int, [
 		c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
 		POINTER(c_int64)]),
@@ -733,3 +735,33 @@ def png_decode(data):
 	out = np.empty((h, w) if c == 1 else (h, w, c), dtype=np.uint8)
 	check(load().ogd_png_decode_u8(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), _ptr(out), w * c))
 	return out
+
+
+def deflate_raw(data):
+	"""A raw deflate stream (zlib.decompress(x, -15) reads it) of `data`: Huffman-coded literals, host code."""
+	data = bytes(data)
+	cap = len(data) + len(data) // 1000 + 64
+	out = ctypes.create_string_buffer(cap)
+	n = c_int64(0)
+	check(load().ogd_deflate_raw(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), ctypes.cast(out, c_void_p), cap, ctypes.byref(n)))
+	return out.raw[:n.value]
+
+
+def deflate_many(members):
+	"""[(deflate stream, crc32)] of a list of bytes objects in one call (the members of a zip archive)."""
+	n = len(members)
+	if n == 0:
+		return []
+	blob = b"".join(members)
+	offsets = np.zeros(n + 1, dtype=np.int64)
+	np.cumsum([len(m) for m in members], out=offsets[1:])
+	cap = len(blob) + len(blob) // 1000 + 64 * n + 64
+	out = ctypes.create_string_buffer(cap)
+	out_offsets = np.zeros(n + 1, dtype=np.int64)
+	crcs = np.zeros(n, dtype=np.uint32)
+	check(load().ogd_deflate_many(
+		ctypes.cast(ctypes.c_char_p(blob), c_void_p), _ptr(offsets), n, ctypes.cast(out, c_void_p), cap,
+		_ptr(out_offsets), _ptr(crcs)))
+	raw = out.raw[:int(out_offsets[-1])]
+	bounds = out_offsets.tolist()
+	return [(raw[a:b], int(c)) for a, b, c in zip(bounds[:-1], bounds[1:], crcs.tolist())]

@@ -111,7 +111,8 @@ class ZipReader:
 
 class ZipWriter:
 	"""writestr(name, data) as zipfile.ZipFile(f, "w", ZIP_DEFLATED) offers it; the archive is assembled in memory
-	and written to `fileobj` by close().  Members beyond the plain format's limits (65 534 members, 4 GiB) make
+	and written to `fileobj` by close() (compresslevel is accepted for zipfile's signature; the deflate writer has no
+	levels).  Members beyond the plain format's limits (65 534 members, 4 GiB) make
 	close() hand everything to the zipfile module, which writes zip64."""
 
 	def __init__(self, fileobj, compression=zipfile.ZIP_DEFLATED, compresslevel=1):
@@ -151,17 +152,19 @@ class ZipWriter:
 		dos_time = t.tm_hour << 11 | t.tm_min << 5 | t.tm_sec // 2
 		dos_date = max(t.tm_year - 1980, 0) << 9 | t.tm_mon << 5 | t.tm_mday
 		out, central, offset = [], [], 0
-		for name, data in self._members:
+		if self._method == zipfile.ZIP_DEFLATED:
+			# libogdewarp's entropy-only deflate (csrc/ogd_deflate.h), all members in one call: coordinate text and
+			# float32 arrays hold next to nothing for a string matcher to find, and zlib's set-up per member alone
+			# costs more than coding a kilobyte
+			from ... import _shim
+			packed = _shim.deflate_many([data for _, data in self._members])
+		else:
+			packed = [(data, zlib.crc32(data)) for _, data in self._members]
+		for (name, data), (body, crc) in zip(self._members, packed):
 			try:
 				raw, flags = name.encode("ascii"), 0
 			except UnicodeEncodeError:
 				raw, flags = name.encode("utf-8"), 0x0800
-			if self._method == zipfile.ZIP_DEFLATED:
-				c = zlib.compressobj(self._level, zlib.DEFLATED, -15)
-				body = c.compress(data) + c.flush()
-			else:
-				body = data
-			crc = zlib.crc32(data)
 			fields = (20, flags, self._method, dos_time, dos_date, crc, len(body), len(data), len(raw), 0)
 			out.append(_LOCAL.pack(b"PK\x03\x04", *fields))
 			out.append(raw)

@@ -16,6 +16,7 @@ on the GPU:
 import io
 import json
 import math
+import os
 import zipfile
 
 import numpy as np
@@ -344,11 +345,18 @@ class Grid:
 		member = io.BytesIO()
 		np.save(member, np.asarray(self._grid_hv, dtype=np.float32), allow_pickle=False)
 		meta = dict(version=1, cell=self._grid_res, shape=self._grid_hv.shape)
-		# deflate level 1: float32 node positions barely shrink at any level (85 %), the default level only
-		# costs more time; method (deflate), member names, order and contents are the reference's
-		with zipfile.ZipFile(path, "w", compression, compresslevel=1) as zf:
-			zf.writestr("data.npy", member.getvalue())
-			zf.writestr("meta.json", json.dumps(meta))
+		# method (deflate), member names, order and contents are the reference's; the deflate streams come from
+		# libogdewarp's entropy-only writer (batch/core/fastzip.py): float32 node positions hold nothing for a string
+		# matcher — zlib spends 14 ms per page finding that out and ends 2 % smaller
+		from .batch.core.fastzip import ZipWriter
+		if isinstance(path, (str, os.PathLike)):
+			with open(path, "wb") as f, ZipWriter(f, compression) as zf:
+				zf.writestr("data.npy", member.getvalue())
+				zf.writestr("meta.json", json.dumps(meta))
+		else:
+			with ZipWriter(path, compression) as zf:
+				zf.writestr("data.npy", member.getvalue())
+				zf.writestr("meta.json", json.dumps(meta))
 
 	@property
 	def transformer(self):

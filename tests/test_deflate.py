@@ -1,0 +1,69 @@
+"""libogdewarp's deflate writer (csrc/ogd_deflate.h, host code) read back by zlib and by the library's own inflate."""
+import io
+import zipfile
+import zlib
+
+import numpy as np
+import pytest
+
+from origami_amd import _shim, synth
+from origami_amd.dewarp import Grid
+
+
+def _cases():
+	rng = np.random.default_rng(2)
+	fib = [1, 1]
+	while len(fib) < 40:
+		fib.append(fib[-1] + fib[-2])
+	skewed = b"".join(bytes([k]) * min(f, 200000) for k, f in enumerate(fib[:27]))  # a Huffman tree deeper than 15 bits
+	return {
+		"empty": b"", "one": b"x", "two": b"xy", "zeros": bytes(100000), "all bytes": bytes(range(256)) * 300,
+		"random": rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(), "text": b"12.5 7001.25, " * 4000,
+		"skewed": skewed, "65534": bytes(rng.integers(48, 58, 65534, dtype=np.uint8)),
+		"65535": bytes(rng.integers(48, 58, 65535, dtype=np.uint8)), "65536": bytes(rng.integers(48, 58, 65536, dtype=np.uint8)),
+		"131071": bytes(rng.integers(0, 3, 131071, dtype=np.uint8)),
+	}
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_deflate_is_read_back_by_zlib_and_by_our_inflate(name):
+	data = _cases()[name]
+	z = _shim.deflate_raw(data)
+	assert zlib.decompress(z, -15) == data
+	framed = b"\x78\x01" + z + zlib.adler32(data).to_bytes(4, "big")
+	assert _shim.inflate_zlib(framed, len(data)).tobytes() == data
+	assert len(z) <= len(data) + len(data) // 1000 + 64
+
+
+def test_deflate_size_against_zlib_on_the_stage_outputs():
+	rng = np.random.default_rng(3)
+	member = io.BytesIO()
+	np.save(member, synth.Warp((6000, 8000), 0.03, 0.025, 1, 2).node_grid(25).astype(np.float32), allow_pickle=False)
+	npy = member.getvalue()
+	ring = synth.polygon_rings(rng, (6000, 8000), 1, mu=20)[0]
+	wkt = ("POLYGON ((" + ", ".join("%.16g %.16g" % (x, y) for x, y in ring) + "))").encode()
+	for data, slack in ((npy, 1.05), (wkt, 1.10)):
+		ours = len(_shim.deflate_raw(data))
+		c = zlib.compressobj(1, zlib.DEFLATED, -15)
+		theirs = len(c.compress(data) + c.flush())
+		assert ours <= slack * theirs, (ours, theirs)
+		assert ours < 0.95 * len(data)
+
+
+def test_deflate_many_and_the_archives_built_from_it(tmp_path):
+	members = [b"", b"POLYGON ((0 0, 1 0, 1 1, 0 0))", bytes(70000), b"abc" * 1000]
+	packed = _shim.deflate_many(members)
+	assert [zlib.decompress(z, -15) for z, _ in packed] == members
+	assert [c for _, c in packed] == [zlib.crc32(m) for m in members]
+	assert _shim.deflate_many([]) == []
+	# Grid.save -> an ordinary deflate zip that zipfile and Grid.open read
+	nodes = synth.Warp((1200, 1600), 0.03, 0.025, 1, 2).node_grid(25)
+	Grid(nodes, 25).save(tmp_path / "dewarp.zip")
+	with zipfile.ZipFile(tmp_path / "dewarp.zip") as zf:
+		assert zf.testzip() is None
+		assert zf.namelist() == ["data.npy", "meta.json"]
+		assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in zf.infolist())
+	np.testing.assert_array_equal(Grid.open(tmp_path / "dewarp.zip").points("sample"), nodes.astype(np.float32))
+	with open(tmp_path / "again.zip", "wb") as f:
+		Grid(nodes, 25).save(f)
+	assert (tmp_path / "again.zip").read_bytes()[:4] == b"PK\x03\x04"
