@@ -9,6 +9,7 @@
 #include "ogd_common.h"
 #include <algorithm>
 #include <cmath>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -26,8 +27,13 @@ void parallel_ranges(int64_t n, int64_t grain, F fn) {
   }
   std::vector<std::thread> pool;
   const int64_t step = (n + want - 1) / want;
-  for (int64_t k = 1; k < want; ++k) pool.emplace_back(fn, k * step, std::min(n, (k + 1) * step));
+  int64_t started = 1;  // ranges 1 .. started - 1 run on threads of their own
+  try {
+    for (; started < want; ++started) pool.emplace_back(fn, started * step, std::min(n, (started + 1) * step));
+  } catch (const std::system_error&) {  // no more threads to be had: the rest runs here
+  }
   fn((int64_t)0, std::min(n, step));
+  for (int64_t k = started; k < want; ++k) fn(k * step, std::min(n, (k + 1) * step));
   for (auto& t : pool) t.join();
 }
 

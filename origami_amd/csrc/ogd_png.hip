@@ -14,6 +14,7 @@
 #include <functional>
 #include <memory>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -160,6 +161,7 @@ void unfilter_worker(UnfilterShared& sh, int worker, int nworkers) {
         }
         break;
       }
+      if (sh.bad_row.load(std::memory_order_relaxed) != -1) return;
       wait_for_decoder();
     }
     const uint8_t* f = sh.raw + (int64_t)y * (sh.rowbytes + 1);
@@ -263,15 +265,31 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
   sh.progress = &progress;
   sh.finished = &finished;
   sh.done = done.get();
-  std::thread decoder([&]() {
+  auto decode = [&]() {
     st = inflate::inflate_zlib(z.data(), (int64_t)z.size(), raw.get(), raw_bytes, &got, false, &stored, &progress);
     finished.store(true, std::memory_order_release);
-  });
+  };
+  auto unfilter = [&](int k, int of) {
+    if (h.channels == 1) unfilter_worker<1>(sh, k, of);
+    else unfilter_worker<3>(sh, k, of);
+  };
   constexpr int NW = 2;
-  std::thread workers[NW];
-  for (int k = 0; k < NW; ++k)
-    workers[k] = h.channels == 1 ? std::thread(unfilter_worker<1>, std::ref(sh), k, NW)
-                                 : std::thread(unfilter_worker<3>, std::ref(sh), k, NW);
+  std::thread decoder, workers[NW];
+  bool threaded = true;
+  try {
+    decoder = std::thread(decode);
+    for (int k = 0; k < NW; ++k) workers[k] = std::thread(unfilter, k, NW);
+  } catch (const std::system_error&) {  // no more threads to be had: stop what did start, then do it all here
+    threaded = false;
+    sh.bad_row.store(-3);
+    for (auto& w : workers)
+      if (w.joinable()) w.join();
+    if (decoder.joinable()) decoder.join();
+    else decode();
+    sh.bad_row.store(-1);
+    for (int y = 0; y < h.height; ++y) done[y].store(0, std::memory_order_relaxed);
+    unfilter(0, 1);
+  }
   for (int64_t at = 0; at < raw_bytes;) {  // Adler-32 of the filtered rows, as far as they are final
     const int64_t ready = progress.load(std::memory_order_acquire);
     if (ready > at) {
@@ -283,8 +301,10 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
       wait_for_decoder();
     }
   }
-  decoder.join();
-  for (auto& w : workers) w.join();
+  if (threaded) {
+    decoder.join();
+    for (auto& w : workers) w.join();
+  }
   const int bad_row = sh.bad_row.load();
   if (st != inflate::OK || got != raw_bytes)
     return fail(OGD_ERR_INVALID, "PNG: image data %s", st == inflate::OUTPUT_FULL ? "longer than the header says"
