@@ -522,3 +522,67 @@ def test_wkt_numbers_equal_printf_16g():
 	got = text[1:-1].replace(",", "").split(" ")
 	want = ["%.16g" % v for v in cases]
 	assert got == want
+
+
+def test_delaunay_points_on_degenerate_sets_is_a_delaunay_triangulation_of_the_hull():
+	"""Small point sets on a coarse integer grid — collinear runs, points on hull edges, cocircular quadruples, twins —
+	checked in exact integer arithmetic: positively oriented triangles that tile the convex hull, every interior edge
+	locally Delaunay, ties counted exactly, twins named; UNSUPPORTED only for collinear input."""
+	from fractions import Fraction
+	rng = np.random.default_rng(21)
+
+	def orient(a, b, c):
+		return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+
+	def hull_area2(points):
+		pts = sorted(set(points))
+		def chain(seq):
+			out = []
+			for p in seq:
+				while len(out) >= 2 and orient(out[-2], out[-1], p) <= 0:
+					out.pop()
+				out.append(p)
+			return out[:-1]
+		ring = chain(pts) + chain(pts[::-1])
+		return sum(ring[k][0] * ring[(k + 1) % len(ring)][1] - ring[(k + 1) % len(ring)][0] * ring[k][1] for k in range(len(ring)))
+
+	n_unsupported = 0
+	for trial in range(400):
+		n = int(rng.integers(3, 40))
+		span = int(rng.choice([2, 3, 5, 9, 30]))
+		ipts = [tuple(int(v) for v in p) for p in rng.integers(0, span + 1, size=(n, 2))]
+		pts = np.array(ipts, dtype=np.float64)
+		distinct = sorted(set(ipts))
+		collinear = len(distinct) < 3 or all(orient(distinct[0], distinct[1], p) == 0 for p in distinct)
+		try:
+			simplices, _, ties, twin = _shim.delaunay_points(pts, twins=True)
+		except _shim.OgdError as e:
+			assert e.status == _shim.ERR_UNSUPPORTED and collinear, (trial, ipts)
+			n_unsupported += 1
+			continue
+		assert not collinear
+		# twins: every dropped point names an earlier, kept point at the same place
+		for i, t in enumerate(twin.tolist()):
+			if t >= 0:
+				assert t < i and twin[t] == -1 and ipts[t] == ipts[i]
+		assert not np.isin(simplices, np.flatnonzero(twin >= 0)).any()
+		area2, edges = 0, {}
+		for t in simplices.tolist():
+			a, b, c = (ipts[v] for v in t)
+			o = orient(a, b, c)
+			assert o > 0, (trial, t)
+			area2 += o
+			for k in range(3):
+				edges.setdefault(frozenset((t[k], t[(k + 1) % 3])), []).append(t)
+		assert area2 == hull_area2(ipts), (trial, ipts)
+		exact_ties = 0
+		for e, ts in edges.items():
+			assert len(ts) <= 2
+			if len(ts) == 2:
+				t, u = ts
+				d = [v for v in u if v not in e][0]
+				s = _exact_incircle(pts[t[0]], pts[t[1]], pts[t[2]], pts[d])
+				assert s <= 0, (trial, sorted(e))
+				exact_ties += s == 0
+		assert ties == exact_ties, (trial, ties, exact_ties)
+	assert 0 < n_unsupported < 200
