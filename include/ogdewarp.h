@@ -128,6 +128,10 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
  * slowly): the caller keeps its own decoder then, too.  _dev: output in device memory.
  */
 int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* supported);
+/* The same from the marker segments alone, without walking the scan (which costs ~1.8 ms for a broadsheet page):
+ * size and component count, and plausible = 0 if the headers already rule the file out.  For callers that size a
+ * buffer and then let the decode call, which parses the whole file once, have the last word (OGD_ERR_UNSUPPORTED). */
+int ogd_jpeg_header(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* plausible);
 /* scan file in -> dewarped page's file out (decode, ogd_dewarp_u8 with C = 1, scale 1, linear, encode: the
  * whole `utils.dewarp` step; only the two files cross PCIe).  OGD_ERR_UNSUPPORTED as ogd_jpeg_decode_gray. */
 int ogd_jpeg_dewarp_jpeg_gray(const uint8_t* file, size_t n, const float* nodes, int h, int w, int s,

@@ -115,6 +115,7 @@ SIGNATURES = {
 		c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
 		POINTER(c_size_t)]),
 	"ogd_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+	"ogd_jpeg_header": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 	"ogd_jpeg_dewarp_jpeg_gray": (c_int, [
 		c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
 	"ogd_page_create_jpeg": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
@@ -307,13 +308,10 @@ def dewarp_jpeg_gray(src, nodes, cell, quality=75):
 def jpeg_dewarp_jpeg_gray(data, nodes, cell, quality=75):
 	"""Scan file -> dewarped page's JPEG file, all on the device; None if the scan is outside the decoder's domain."""
 	buf = np.frombuffer(data, dtype=np.uint8)
-	H, W, nc, ok = jpeg_info(data)
-	if not ok:
-		return None
 	nodes = _c(nodes, np.float32)
 	h, w = nodes.shape[:2]
 	lib = load()
-	try:
+	try:  # the library parses the file once and answers ERR_UNSUPPORTED for what ogd_jpeg_info calls unsupported
 		return _jpeg_call(
 			lambda out, cap, size: lib.ogd_jpeg_dewarp_jpeg_gray(
 				_ptr(buf), buf.size, _ptr(nodes), h, w, int(cell), int(quality), out, cap, size),
@@ -332,12 +330,21 @@ def jpeg_info(data):
 	return H.value, W.value, nc.value, bool(ok.value)
 
 
+def jpeg_header(data):
+	"""(H, W, components, plausible) from the marker segments alone (the scan is not walked: that is the decode call's
+	single pass over the file)."""
+	buf = np.frombuffer(data, dtype=np.uint8)
+	H, W, nc, ok = c_int(0), c_int(0), c_int(0), c_int(0)
+	check(load().ogd_jpeg_header(_ptr(buf), buf.size, ctypes.byref(H), ctypes.byref(W), ctypes.byref(nc), ctypes.byref(ok)))
+	return H.value, W.value, nc.value, bool(ok.value)
+
+
 def jpeg_decode_gray(data):
 	"""np.array(PIL.Image.open(file)) for a baseline JPEG (grayscale, or YCbCr converted to "L" as PIL does), decoded on
 	the device; None if the file is outside the decoder's domain (progressive, restart intervals, CMYK ...: the
 	caller keeps PIL)."""
 	buf = np.frombuffer(data, dtype=np.uint8)
-	H, W, nc, ok = jpeg_info(data)
+	H, W, nc, ok = jpeg_header(data)
 	if not ok:
 		return None
 	out = np.empty((H, W), dtype=np.uint8)
@@ -365,7 +372,7 @@ class DevicePage:
 	def from_jpeg(cls, data):
 		"""The page of a grayscale baseline JPEG scan, decoded straight into device memory; None for any other
 		file (decode it on the host and use DevicePage(pixels))."""
-		H, W, nc, ok = jpeg_info(data)
+		H, W, nc, ok = jpeg_header(data)
 		if not ok:
 			return None
 		buf = np.frombuffer(data, dtype=np.uint8)

@@ -64,6 +64,9 @@ inline hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t sp
   return hipMemcpy2D(dst, dpitch, src, spitch, width, rows, kind);
 }
 
+// ogd_jpeg_dec.hip: parse a scan file once and decode it into `dimg` (allocated here: H * W bytes, packed rows)
+int jpeg_decode_gray_to(DevBuf& dimg, const uint8_t* file, size_t n, int* H, int* W, void* stream);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int check_launch(const char* what) {

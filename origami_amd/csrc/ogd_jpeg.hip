@@ -554,21 +554,14 @@ int ogd_jpeg_dewarp_jpeg_gray(const uint8_t* file, size_t n, const float* nodes,
   OGD_REQUIRE(file && nodes && out_size, "null pointer");
   OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
   OGD_REQUIRE((int64_t)h * s < 32768 && (int64_t)w * s < 32768, "dense grid too large");
-  int H = 0, W = 0, ncomp = 0, supported = 0;
-  OGD_TRY(ogd_jpeg_info(file, n, &H, &W, &ncomp, &supported));
-  if (!supported) {
-    const std::string why = ogd_last_error();  // fail() rewrites the buffer ogd_last_error() points to
-    return fail(OGD_ERR_UNSUPPORTED, "%s", why.c_str());
-  }
-  OGD_REQUIRE(H < 32768 && W < 32768, "scan %dx%d exceeds the int16 coordinate range of remap", W, H);
-  OGD_TRY(ensure_device());
-  const int Hd = h * s, Wd = w * s;
+  int H = 0, W = 0;
   DevBuf dsrc, dnodes, ddst;
-  OGD_TRY(dsrc.alloc((size_t)H * W));
+  OGD_TRY(jpeg_decode_gray_to(dsrc, file, n, &H, &W, nullptr));  // one parse of the file; UNSUPPORTED as ogd_jpeg_info
+  OGD_REQUIRE(H < 32768 && W < 32768, "scan %dx%d exceeds the int16 coordinate range of remap", W, H);
+  const int Hd = h * s, Wd = w * s;
   OGD_TRY(dnodes.alloc((size_t)h * w * 2 * sizeof(float)));
   OGD_TRY(ddst.alloc((size_t)Hd * Wd));
   OGD_HIP(hipMemcpy(dnodes.p, nodes, (size_t)h * w * 2 * sizeof(float), hipMemcpyHostToDevice));
-  OGD_TRY(ogd_jpeg_decode_gray_dev(file, n, dsrc.as<uint8_t>(), H, W, W, nullptr));
   OGD_TRY(ogd_dewarp_u8_dev(dsrc.as<uint8_t>(), H, W, 1, W, dnodes.as<float>(), h, w, s, 1.f, 1.f, ddst.as<uint8_t>(),
                             Wd, OGD_INTER_LINEAR, nullptr));
   return jpeg_encode_dev(ddst.as<uint8_t>(), Hd, Wd, Wd, quality, out, cap, out_size, nullptr);

@@ -642,9 +642,9 @@ struct JpegInfo {
     return OGD_OK;        \
   } while (0)
 
-// Parses the marker segments.  Returns OGD_ERR_INVALID for something that is not a JPEG file at all; a valid
+// Parses the marker segments (headers_only: up to the start of the scan, without walking it).  Returns OGD_ERR_INVALID for something that is not a JPEG file at all; a valid
 // file this decoder does not cover leaves info.supported = false with the reason in info.why.
-static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
+static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, bool headers_only = false) {
   OGD_REQUIRE(n >= 4 && f[0] == 0xFF && f[1] == 0xD8, "not a JPEG file (no SOI marker)");
   uint8_t qt[4][64];
   bool have_q[4] = {false, false, false, false};
@@ -755,6 +755,10 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info) {
   if (info.ncomp == 3 && !have_jfif) JP_UNSUP("three components without a JFIF header (colour space not certain)");
   for (int c = 0; c < info.ncomp; ++c)
     OGD_REQUIRE(have_q[tq[c]] && hd[td[c]].n >= 0 && ha[ta[c]].n >= 0, "JPEG scan refers to a table that was not defined");
+  if (headers_only) {  // size and kind are known; whether the scan itself is in order is the decode call's business
+    info.supported = true;
+    return OGD_OK;
+  }
   // the entropy-coded segment ends at the first marker that is not stuffing
   size_t e = p;
   uint64_t nstuff = 0;  // stuffed zero bytes so far
@@ -1037,6 +1041,19 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
 }
 
 }  // namespace
+// For ogd_jpeg_dewarp_jpeg_gray (ogd_jpeg.hip): parse ONCE (finding the end of a broadsheet scan is a walk over
+// every 0xFF of 6 MB, 1.8 ms), then decode into a buffer of the right size.  OGD_ERR_UNSUPPORTED as ogd_jpeg_info says.
+int jpeg_decode_gray_to(DevBuf& dimg, const uint8_t* file, size_t n, int* H, int* W, void* stream) {
+  JpegInfo info;
+  OGD_TRY(parse_jpeg(file, n, info));
+  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
+  OGD_TRY(ensure_device());
+  OGD_TRY(dimg.alloc((size_t)info.H * info.W));
+  *H = info.H;
+  *W = info.W;
+  return decode_to_device(file, info, dimg.as<uint8_t>(), info.W, as_stream(stream));
+}
+
 }  // namespace ogd
 
 using namespace ogd;
@@ -1051,6 +1068,18 @@ int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int
   *W = info.W;
   *ncomp = info.ncomp;
   *supported = info.supported ? 1 : 0;
+  if (!info.supported) set_error("JPEG decoder: %s", info.why);
+  return OGD_OK;
+}
+
+int ogd_jpeg_header(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* plausible) {
+  OGD_REQUIRE(file && H && W && ncomp && plausible, "null pointer");
+  JpegInfo info;
+  OGD_TRY(parse_jpeg(file, n, info, true));
+  *H = info.H;
+  *W = info.W;
+  *ncomp = info.ncomp;
+  *plausible = info.supported ? 1 : 0;
   if (!info.supported) set_error("JPEG decoder: %s", info.why);
   return OGD_OK;
 }
