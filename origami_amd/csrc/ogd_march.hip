@@ -57,7 +57,9 @@ __device__ __forceinline__ float2 field_dir(const FieldView& f, float px, float 
   double ang = f.phi0;
   if (!f.constant) eval_point_hint<1>(f.inner, f.has_inner, f.extra, f.b, (double)px, (double)py, &ang, hint);
   const float a = (float)ang;  // np.cos(angles, dtype=float32) casts first
-  return make_float2((float)cos((double)a), (float)sin((double)a));
+  double sn, cs;
+  sincos((double)a, &sn, &cs);  // one range reduction for both; a walk is a chain of these, nothing hides their latency
+  return make_float2((float)cs, (float)sn);
 }
 
 __device__ __forceinline__ float2 euler_step(float2 p, float2 d, float len) {
