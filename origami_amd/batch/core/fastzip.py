@@ -68,6 +68,8 @@ class ZipReader:
 		self._zf = None
 		try:
 			self._members = {m[0]: m for m in _scan(self._buf)}
+		except struct.error:  # a directory or header that runs past the end of the file
+			raise zipfile.BadZipFile("Truncated zip file")
 		except _Fallback:
 			self._zf = zipfile.ZipFile(io.BytesIO(self._buf), "r")
 			self._members = dict.fromkeys(self._zf.namelist())

@@ -52,6 +52,13 @@ def test_reader_hands_unusual_archives_to_zipfile_and_rejects_damage():
 	assert fastzip.ZipReader(f.getvalue()).read("a.txt") == b"hello " * 100
 	with pytest.raises(zipfile.BadZipFile):
 		fastzip.ZipReader(b"not a zip file at all")
+	whole = io.BytesIO()
+	with fastzip.ZipWriter(whole) as zf:
+		zf.writestr("a.txt", b"hello " * 100)
+		zf.writestr("b.txt", b"world " * 100)
+	eocd = whole.getvalue()[-22:]
+	with pytest.raises(zipfile.BadZipFile):  # the end record alone: its directory lies before the start of the data
+		fastzip.ZipReader(eocd)
 	g = io.BytesIO()
 	with fastzip.ZipWriter(g) as zf:
 		zf.writestr("a.txt", b"hello " * 100)
