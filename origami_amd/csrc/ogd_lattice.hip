@@ -17,6 +17,7 @@
 #include "ogd_common.h"
 #include "ogd_lawson.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -185,26 +186,39 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   // 1. the lattice quads, two positively oriented triangles each
   const int sgn = L.orient(id(0, 0), id(0, 1), id(1, 1));
   if (sgn == 0) OGD_UNSUPPORTED("degenerate first lattice cell");
-  T.clear();
-  T.reserve((size_t)6 * n);
   // split[cell]: 0 = diagonal a-c, triangles (a, b, c), (a, c, d); 1 = diagonal b-d, triangles (a, b, d), (b, c, d).
   // A convex cell gets the diagonal that is Delaunay for its own four nodes (a-c on a tie), which leaves the
-  // flips below little to do on a smooth warp.
-  std::vector<uint8_t> split((size_t)(h - 1) * (w - 1));
-  for (int i = 0; i + 1 < h; ++i)
-    for (int j = 0; j + 1 < w; ++j) {
-      int a = id(i, j), b = id(i, j + 1), c = id(i + 1, j + 1), d = id(i + 1, j);
-      if (sgn < 0) std::swap(b, d);  // mirrored lattice: (a, d, c, b) is the positive order
-      const bool ac = L.orient(a, b, c) > 0 && L.orient(a, c, d) > 0;
-      const bool bd = L.orient(a, b, d) > 0 && L.orient(b, c, d) > 0;
-      if (!ac && !bd) OGD_UNSUPPORTED("lattice cell (%d, %d) is folded or degenerate", i, j);
-      const bool use_bd = ac && bd ? L.incircle(a, b, c, d) > 0 : bd;
-      split[(size_t)i * (w - 1) + j] = use_bd;
-      if (use_bd)
-        T.insert(T.end(), {a, b, d, b, c, d});
-      else
-        T.insert(T.end(), {a, b, c, a, c, d});
-    }
+  // flips below little to do on a smooth warp.  Cells are independent: rows of cells go to a few threads.
+  const int cw0 = w - 1, ch0 = h - 1;
+  std::vector<uint8_t> split((size_t)ch0 * cw0);
+  T.assign((size_t)6 * ch0 * cw0, 0);
+  T.reserve((size_t)6 * n);
+  std::atomic<int> folded{-1};  // first cell (row-major index) found folded or degenerate
+  parallel_ranges(ch0, 32, [&](int64_t i0, int64_t i1) {
+    for (int i = (int)i0; i < (int)i1; ++i)
+      for (int j = 0; j < cw0; ++j) {
+        int a = id(i, j), b = id(i, j + 1), c = id(i + 1, j + 1), d = id(i + 1, j);
+        if (sgn < 0) std::swap(b, d);  // mirrored lattice: (a, d, c, b) is the positive order
+        const bool ac = L.orient(a, b, c) > 0 && L.orient(a, c, d) > 0;
+        const bool bd = L.orient(a, b, d) > 0 && L.orient(b, c, d) > 0;
+        const int cell = i * cw0 + j;
+        if (!ac && !bd) {
+          int seen = folded.load();
+          while ((seen < 0 || cell < seen) && !folded.compare_exchange_weak(seen, cell)) {
+          }
+          continue;
+        }
+        const bool use_bd = ac && bd ? L.incircle(a, b, c, d) > 0 : bd;
+        split[(size_t)cell] = use_bd;
+        int32_t* t = &T[(size_t)6 * cell];
+        if (use_bd) {
+          t[0] = a; t[1] = b; t[2] = d; t[3] = b; t[4] = c; t[5] = d;
+        } else {
+          t[0] = a; t[1] = b; t[2] = c; t[3] = a; t[4] = c; t[5] = d;
+        }
+      }
+  });
+  if (folded.load() >= 0) OGD_UNSUPPORTED("lattice cell (%d, %d) is folded or degenerate", folded.load() / cw0, folded.load() % cw0);
 
   // 2. outline in positive order
   std::vector<int> ring;
@@ -287,24 +301,33 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
     // neighbour cell across side ab, bc, cd, da as (di, dj); mirrored lattices have b below a instead of right of it
     const int di[2][4] = {{-1, 0, 1, 0}, {0, 1, 0, -1}}, dj[2][4] = {{0, 1, 0, -1}, {-1, 0, 1, 0}};
     const int mir = sgn < 0;
-    for (int i = 0; i < ch; ++i)
-      for (int j = 0; j < cw; ++j) {
-        const int c = i * cw + j, sp = split[c];
-        N[3 * (2 * c) + (sp ? 0 : 1)] = 2 * c + 1;
-        N[3 * (2 * c + 1) + (sp ? 1 : 2)] = 2 * c;
-        for (int side = 0; side < 4; ++side) {
-          const int slot = 3 * (2 * c + side_tri[sp][side]) + side_slot[sp][side];
-          const int ni = i + di[mir][side], nj = j + dj[mir][side];
-          if (ni < 0 || nj < 0 || ni >= ch || nj >= cw) {  // outline: a pocket triangle or nothing
+    auto cell_links = [&](int i, int j, std::vector<HalfEdge>* outline) {
+      const int c = i * cw + j, sp = split[c];
+      N[3 * (2 * c) + (sp ? 0 : 1)] = 2 * c + 1;
+      N[3 * (2 * c + 1) + (sp ? 1 : 2)] = 2 * c;
+      for (int side = 0; side < 4; ++side) {
+        const int slot = 3 * (2 * c + side_tri[sp][side]) + side_slot[sp][side];
+        const int ni = i + di[mir][side], nj = j + dj[mir][side];
+        if (ni < 0 || nj < 0 || ni >= ch || nj >= cw) {  // outline: a pocket triangle or nothing
+          if (outline) {
             const int t = slot / 3, k = slot % 3;
             const uint32_t x = (uint32_t)T[3 * t + (k + 1) % 3], y = (uint32_t)T[3 * t + (k + 2) % 3];
-            he.push_back({((uint64_t)std::min(x, y) << 32) | std::max(x, y), slot});
-            continue;
+            outline->push_back({((uint64_t)std::min(x, y) << 32) | std::max(x, y), slot});
           }
-          const int nc = ni * cw + nj, nsp = split[nc], nside = (side + 2) % 4;
-          N[slot] = 2 * nc + side_tri[nsp][nside];
+          continue;
         }
+        const int nc = ni * cw + nj, nsp = split[nc], nside = (side + 2) % 4;
+        N[slot] = 2 * nc + side_tri[nsp][nside];
       }
+    };
+    // the cells on the rim here (their outline sides go through the sort below), the inner rows on a few threads
+    for (int i = 0; i < ch; ++i)
+      for (int j = 0; j < cw; ++j)
+        if (i == 0 || j == 0 || i == ch - 1 || j == cw - 1) cell_links(i, j, &he);
+    parallel_ranges(ch, 32, [&](int64_t i0, int64_t i1) {
+      for (int i = std::max<int>((int)i0, 1); i < std::min<int>((int)i1, ch - 1); ++i)
+        for (int j = 1; j < cw - 1; ++j) cell_links(i, j, nullptr);
+    });
     for (int t = 2 * ch * cw; t < nt; ++t)
       for (int k = 0; k < 3; ++k) {
         const uint32_t x = (uint32_t)T[3 * t + (k + 1) % 3], y = (uint32_t)T[3 * t + (k + 2) % 3];
@@ -323,24 +346,21 @@ int lattice_delaunay(const double* pts, int h, int w, std::vector<int32_t>& T, s
   // 6. Lawson flips until every interior edge is locally Delaunay
   // The first look at every interior edge is independent of the others: done on a few threads, and only the
   // edges that fail go on the flip stack (a flip pushes the edges whose quadrilateral it changed).
-  std::vector<int32_t> edges;
-  edges.reserve((size_t)3 * nt / 2);
-  for (int s = 3 * nt - 1; s >= 0; --s)
-    if (N[s] > s / 3) edges.push_back(s);
-  std::vector<uint8_t> bad(edges.size(), 0);
-  parallel_ranges((int64_t)edges.size(), 16384, [&](int64_t e0, int64_t e1) {
-    for (int64_t e = e0; e < e1; ++e) {
-      const int s = edges[e], t = s / 3, k = s % 3, u = N[s];
+  std::vector<uint8_t> bad((size_t)3 * nt, 0);
+  parallel_ranges((int64_t)3 * nt, 32768, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1; ++s) {
+      const int t = (int)(s / 3), k = (int)(s % 3), u = N[s];
+      if (u <= t) continue;  // hull edge, or the edge is looked at from its other triangle
       const int a = T[3 * t + k], b = T[3 * t + (k + 1) % 3], c = T[3 * t + (k + 2) % 3];
       int d = -1;
       for (int j = 0; j < 3; ++j)
         if (T[3 * u + j] != b && T[3 * u + j] != c) d = T[3 * u + j];
-      bad[e] = d < 0 || L.incircle(a, b, c, d) > 0;
+      bad[s] = d < 0 || L.incircle(a, b, c, d) > 0;
     }
   });
   std::vector<int32_t> stack;
-  for (size_t e = 0; e < edges.size(); ++e)
-    if (bad[e]) stack.push_back(edges[e]);
+  for (int s = 3 * nt - 1; s >= 0; --s)
+    if (bad[s]) stack.push_back(s);
   int64_t flips = 0;
   const int64_t max_flips = (int64_t)nt * 64 + 1024;  // Lawson terminates; this only guards a logic error
   OGD_TRY(lawson_flips(L, T, N, stack, flips, max_flips, nullptr));
