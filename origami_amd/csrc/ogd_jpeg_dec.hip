@@ -22,7 +22,8 @@
 //                     rounds.  The host stops when a round changes no state.  From the second round on only chunks
 //                     whose entry changed (or whose exit another thread's forward walk wrote) are walked again.
 //                     With restart intervals a walk that ends an MCU just in front of an interval start (host
-//                     list) continues there with a fresh block.
+//                     list) continues there with a fresh block.  Blank paper (a periodic bit string: period_kernel)
+//                     is crossed by arithmetic instead of look-ups.
 //   D3 scan of the blocks completed per chunk -> first block of every chunk
 //   D4 decode_chunks<WRITE>  the same walk, now storing DC differences and AC coefficients
 //   D5 inclusive scan of the DC differences per component (hipCUB; restart intervals: minus the sum in front
@@ -159,6 +160,42 @@ __device__ __forceinline__ int decode_symbol(const uint16_t* __restrict__ look8,
   return 0;
 }
 
+// Blank paper is the stream's hard case: every MCU the same few bits, a parse at the wrong phase is self-consistent,
+// and the right one has to be carried in from the last printed block by ONE walk.  That walk need not decode: where
+// the bit string has period q and an MCU of L bits (q | L) has just been decoded inside the periodic stretch, the
+// MCUs that follow are the same bits, so they end at multiples of L — arithmetic instead of Huffman look-ups.
+// period_kernel finds the stretches: per[c] = the smallest q <= 32 with bit[j] == bit[j + q] for all j in the
+// window [512 c, 512 c + PERIOD_WINDOW) of chunk c, 0 if there is none (or the window would pass the end of the
+// stream).  The window reaches LATTICE_MAX bits past an MCU that begins in front of the next chunk border, so a walk
+// that enters chunk c + 1 on the lattice finds its first MCU there covered by chunk c's window and the following ones
+// by chunk c + 1's.
+constexpr int PERIOD_WINDOW = CHUNK_BITS + 128;  // whole 64-bit words
+constexpr int LATTICE_MAX = 64;                   // longest MCU taken as a lattice step: 2 * LATTICE_MAX <= 128
+
+__global__ __launch_bounds__(256) void period_kernel(const uint8_t* __restrict__ s, uint64_t total_bits, int nchunk,
+                                                     uint8_t* __restrict__ per /* [nchunk + 16] */) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunk + 16) return;
+  uint32_t q = 0;
+  if (i < nchunk && (uint64_t)i * CHUNK_BITS + PERIOD_WINDOW + 64 <= total_bits) {
+    const uint64_t* wp = reinterpret_cast<const uint64_t*>(s + (size_t)i * (CHUNK_BITS / 8));  // 64-byte aligned
+    uint64_t a = __builtin_bswap64(wp[0]), b = __builtin_bswap64(wp[1]);
+    uint32_t cand = 0;
+#pragma unroll
+    for (int k = 1; k <= 32; ++k) cand |= (uint32_t)(a == ((a << k) | (b >> (64 - k)))) << (k - 1);
+    for (int t = 1; t < PERIOD_WINDOW / 64 && cand; ++t) {  // text: cand is 0 after the first word
+      a = b;
+      b = __builtin_bswap64(wp[t + 1]);
+      for (uint32_t rest = cand; rest; rest &= rest - 1) {
+        const int k = __ffs((int)rest);
+        if (a != ((a << k) | (b >> (64 - k)))) cand &= ~(1u << (k - 1));
+      }
+    }
+    if (cand) q = (uint32_t)__ffs((int)cand);
+  }
+  per[i] = (uint8_t)q;
+}
+
 struct ChunkState {
   uint64_t p;  // bit position of the next symbol
   int32_t k;   // index of the next coefficient of the current block (0: a DC symbol comes next)
@@ -182,7 +219,9 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
                                                             int16_t* __restrict__ coef, int32_t* __restrict__ dcdiff,
                                                             int forward, const uint64_t* __restrict__ rst_bits, int nrst,
                                                             int restart, int* __restrict__ rst_check,
-                                                            const uint8_t* __restrict__ dirty, uint8_t* __restrict__ touched) {
+                                                            const uint8_t* __restrict__ dirty, uint8_t* __restrict__ touched,
+                                                            const uint8_t* __restrict__ per) {
+  constexpr bool LATTICE = !WRITE;  // the state passes: see period_kernel
   __shared__ DecTables t;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs);
@@ -196,6 +235,9 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
   // has written since, would reproduce that exit: skipped (shift_states_kernel keeps the books).
   if (!WRITE && !dirty[i]) return;
   uint64_t end = min((uint64_t)(i + 1) * CHUNK_BITS, total_bits);
+  // The write pass stops where the state pass left the chunk, which is where the next chunk's thread begins: a
+  // lattice step (below) ends on an MCU border, up to an MCU past the first symbol border behind the chunk.
+  if (WRITE && i + 1 < nchunk) end = entry[i + 1].p;
   ChunkState st = entry[i];
   uint64_t p = st.p;
   int k = st.k, m = MULTI ? st.m : 0;
@@ -237,10 +279,14 @@ __global__ __launch_bounds__(256) void decode_chunks_kernel(const uint8_t* __res
     }
   };
   select_block();
-  uint64_t pb = ~0ull;  // where the current block began (if on this walk)
+  uint64_t pb = ~0ull;  // where the current MCU began (if on this walk)
+  uint32_t lat = 0, qlat = 0;  // the walk left its last chunk on a lattice of MCUs of `lat` bits, period qlat | lat
+  uint32_t qc = 0;             // per[c]
+  int walked = 0;              // chunks after the walk's own that were decoded (lattice chunks are not counted)
   // one 64-bit load serves several symbols: w0 holds >= 57 valid bits from bit p0 on, a symbol takes <= 31
   uint64_t p0 = p, w0 = window(s, p);
 walk:
+  if (LATTICE) qc = per[c];
   while (p < end) {
     if (p - p0 > 57 - 31) {
       p0 = p;
@@ -249,7 +295,7 @@ walk:
     const uint64_t w = w0 << (p - p0);
     int len;
     if (k == 0) {
-      pb = p;
+      if (!MULTI || m == 0) pb = p;
       const int sz = decode_symbol(hd->look8, hd->maxcode, hd->valoff, hd->vals, w, len) & 15;
       if (WRITE && mcu < nmcu) {
         int v = 0;
@@ -291,26 +337,16 @@ walk:
           ++mcu;
         }
         select_block();
-        if (!WRITE && !MULTI && !RST && pb != ~0ull && p - pb <= 28) {
-          // Blank paper: the same few bits block after block.  A block's parse is a function of exactly the bits
-          // it consumed, so while the next L bits repeat them the next block ends L bits on — counted without
-          // decoding, several per load, as long as it ends inside the chunk (where the plain walk would stop too).
-          const uint32_t L = (uint32_t)(p - pb);
-          const uint64_t pat = window(s, pb) >> (64 - L);
-          const uint32_t per_load = 57u / L;
-          for (;;) {
-            const uint64_t wq = window(s, p);
-            uint32_t j = 0;
-            while (j < per_load && p + L <= end && ((wq << (j * L)) >> (64 - L)) == pat) {
-              ++j;
-              p += L;
-            }
-            blocks += j;
-            if (j < per_load) break;
-          }
-        }
         if (RST && m == 0) {
-          while (next_rst < p) {  // passed without a restart: this walk is on a wrong parse
+          if (next_rst < p) {  // passed without a restart: this walk is on a wrong parse
+            while (ri + 1 < nrst && rst_bits[ri + 1] <= p) ++ri;
+            // The right parse begins a fresh MCU at every interval start, whatever came before: a state pass goes
+            // back to the last one it has passed and is exact from there on (its block count is not, but a walk
+            // from an exact entry state never comes here, and that walk writes the count that is used).
+            if (!WRITE) {
+              p = rst_bits[ri];
+              pb = ~0ull;
+            }
             ++ri;
             next_rst = ri < nrst ? rst_bits[ri] : ~0ull;
           }
@@ -321,8 +357,45 @@ walk:
               if (mcu != (int64_t)(ri + 1) * restart) misplaced = true;
             }
             p = next_rst;
+            pb = ~0ull;  // the MCU in front of p does not end at p
             ++ri;
             next_rst = ri < nrst ? rst_bits[ri] : ~0ull;
+          }
+        }
+        if (LATTICE && m == 0) lat = 0;
+        if (LATTICE && m == 0 && pb != ~0ull) {
+          const uint64_t L64 = p - pb;
+          // (with restart intervals: only if no interval can begin in the stretch — an MCU that ends less than 8
+          // bits in front of one is followed by the interval, not by the next period)
+          if (qc != 0 && L64 <= LATTICE_MAX && pb >= (uint64_t)c * CHUNK_BITS && (uint32_t)L64 % qc == 0 &&
+              (!RST || next_rst >= end + LATTICE_MAX + 8)) {
+            // an MCU inside a periodic window, a whole number of periods long: the rest of the chunk repeats it
+            lat = (uint32_t)L64;
+            qlat = qc;
+            if (p < end) {
+              const uint32_t n = ((uint32_t)(end - p) + lat - 1) / lat;
+              p += (uint64_t)n * lat;
+              blocks += (uint64_t)n * (uint64_t)bpm;
+            }
+          } else {
+            if (!MULTI && !RST && L64 <= 28) {
+              // No periodic window (the margin between two printed lines, shorter than a chunk): a block's parse is
+              // a function of exactly the bits it consumed, so while the next L bits repeat them the next block ends
+              // L bits on — counted without decoding, several per load, as long as it ends inside the chunk.
+              const uint32_t L = (uint32_t)L64;
+              const uint64_t pat = window(s, pb) >> (64 - L);
+              const uint32_t per_load = 57u / L;
+              for (;;) {
+                const uint64_t wq = window(s, p);
+                uint32_t j = 0;
+                while (j < per_load && p + L <= end && ((wq << (j * L)) >> (64 - L)) == pat) {
+                  ++j;
+                  p += L;
+                }
+                blocks += j;
+                if (j < per_load) break;
+              }
+            }
           }
         }
       }
@@ -357,16 +430,55 @@ walk:
     if (c == i || !same) nblocks[c] = blocks;
     // Where the stream is periodic (a blank margin: every block the same six bits) a wrong parse can be
     // self-consistent, walks never re-synchronise and exactness would advance one chunk per round.  So a walk
-    // that arrives at a border in a state other than the published one carries that state on through the
-    // following chunks (up to `forward` of them: none in the first rounds, when most published states are still
-    // guesses, then doubling) instead of waiting for the next round.  Several threads may then write one
-    // chunk's state in a round; whatever survives is only a better or worse guess — the loop on the host ends
-    // only after a round in which every chunk reproduced its published state from its predecessor's.
-    if (!same && c + 1 < nchunk && c - i < forward && p < total_bits) {
+    // that arrives at a border in a state other than the published one carries that state on instead of waiting
+    // for the next round: by arithmetic through chunks on its lattice (in any round), by decoding through up to
+    // `forward` other chunks (none in the first rounds, when most published states are still guesses, then
+    // doubling).  Several threads may then write one chunk's state in a round; whatever survives is only a better
+    // or worse guess — the loop on the host ends only after a round in which every chunk reproduced its published
+    // state from its predecessor's.
+    if (!same && c + 1 < nchunk && p < total_bits) {
       ++c;
-      blocks = 0;
-      end = min((uint64_t)(c + 1) * CHUNK_BITS, total_bits);
-      goto walk;
+      if (LATTICE && lat != 0) {
+        // On the lattice (k == 0, m == 0, the MCU in front of p lies in a window of period qlat): chunks whose
+        // window has that period are crossed eight flags per load.  Their states are written without looking at
+        // the published ones; `touched` sends each chunk's own thread over them next round.
+        typedef uint64_t u64u __attribute__((aligned(1)));
+        for (;;) {
+          const uint64_t flags = *reinterpret_cast<const u64u*>(per + c);
+          int nok = 0;
+          while (nok < 8 && (uint32_t)((flags >> (8 * nok)) & 255u) == qlat) ++nok;
+          for (int j = 0; j < nok; ++j, ++c) {  // per[] is 0 from the last chunks on: c stays below nchunk - 1
+            const uint64_t border = (uint64_t)(c + 1) * CHUNK_BITS;
+            if (RST && next_rst < border + LATTICE_MAX + 8) {  // an interval may begin here: decoded, not stepped over
+              nok = 0;
+              break;
+            }
+            uint32_t n = 0;
+            if (p < border) {
+              n = ((uint32_t)(border - p) + lat - 1) / lat;
+              p += (uint64_t)n * lat;
+            }
+            ChunkState ns;
+            ns.p = p;
+            ns.k = 0;
+            ns.m = 0;
+            exit_state[c] = ns;
+            nblocks[c] = (uint64_t)n * (uint64_t)bpm;
+            touched[c] = 1;
+          }
+          if (nok < 8) break;
+        }
+        pb = ~0ull;
+      }
+      lat = 0;
+      if (walked < forward) {  // otherwise chunk c's own thread takes over next round: its entry has changed
+        ++walked;
+        blocks = 0;
+        end = min((uint64_t)(c + 1) * CHUNK_BITS, total_bits);
+        p0 = p;
+        w0 = window(s, p);
+        goto walk;
+      }
     }
   }
 }
@@ -385,41 +497,45 @@ __global__ __launch_bounds__(256) void dc_restart_fix_kernel(const int32_t* __re
 }
 
 // entry[i] = exit[i - 1] for the next round; entry[0] stays (0, 0).  dirty[i]: chunk i has to be walked again — its
-// entry changed, or a forward walk of another thread wrote its exit state in the round before.
+// entry changed, or a forward walk of another thread wrote its exit state in the round before, or it has not been
+// walked yet (init_states_kernel).  A predecessor that has not been walked yet leaves the entry at its first guess.
 __global__ __launch_bounds__(256) void shift_states_kernel(const ChunkState* __restrict__ exit_state, int nchunk,
                                                            ChunkState* __restrict__ entry, uint8_t* __restrict__ dirty,
                                                            uint8_t* __restrict__ touched) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunk) return;
+  const ChunkState old = entry[i];
   ChunkState z;
   z.p = 0;
   z.k = 0;
   z.m = 0;
   if (i > 0) z = exit_state[i - 1];
-  const ChunkState old = entry[i];
-  dirty[i] = (uint8_t)(touched[i] || old.p != z.p || old.k != z.k || old.m != z.m);
+  if (z.p == ~0ull) z = old;
+  dirty[i] = (uint8_t)(touched[i] || old.p != z.p || old.k != z.k || old.m != z.m || exit_state[i].p == ~0ull);
   touched[i] = 0;
   entry[i] = z;
 }
 
+// First guess: every chunk begins a block at its border.  Chunks inside a periodic stretch (per[i] == per[i - 1] != 0)
+// sit the first round out: the chunk at the head of the stretch crosses them on its lattice, so their states come
+// from ONE guess and agree with each other — guessed one by one (each border is another phase of the period) they
+// would change with every round and keep overwriting what the one walk with the right state writes.
 __global__ __launch_bounds__(256) void init_states_kernel(int nchunk, ChunkState* __restrict__ entry,
                                                           ChunkState* __restrict__ exit_state,
                                                           uint64_t* __restrict__ nblocks, uint8_t* __restrict__ dirty,
-                                                          uint8_t* __restrict__ touched) {
+                                                          uint8_t* __restrict__ touched, const uint8_t* __restrict__ per) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i > nchunk) return;
-  if (i == nchunk) {
-    nblocks[i] = 0;  // sentinel of the scan
-    return;
-  }
+  nblocks[i] = 0;  // [nchunk]: sentinel of the scan
+  if (i == nchunk) return;
   ChunkState z;
   z.p = (uint64_t)i * CHUNK_BITS;
   z.k = 0;
   z.m = 0;
   entry[i] = z;
-  z.p = ~0ull;
+  z.p = ~0ull;  // not walked yet
   exit_state[i] = z;
-  dirty[i] = 1;
+  dirty[i] = (uint8_t)!(per != nullptr && i > 0 && per[i] != 0 && per[i] == per[i - 1]);
   touched[i] = 0;
 }
 
@@ -820,9 +936,6 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, bool headers_o
   T.base[1] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0) : 0;
   T.base[2] = info.ncomp == 3 ? (int32_t)(nmcu * T.n0 + nmcu) : 0;
   T.ntot = (int32_t)(nmcu * T.bpm);
-  // A large one-component scan of less than a byte per block is a blank page: every block the same six bits, chunk
-  // walks never re-synchronise (single lanes walk the stream: 99 ms for 12 MP) and libjpeg is at its fastest (8 ms).
-  if (info.ncomp == 1 && nmcu > 65536 && (int64_t)(e - p) < nmcu) JP_UNSUP("blank page (less than a byte per block): libjpeg is faster");
   if (restart > 0) {
     const int64_t nint = (nmcu + restart - 1) / restart;
     if ((int64_t)info.rst.size() + 1 != nint) JP_UNSUP("number of restart markers does not match the image");
@@ -932,12 +1045,19 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   uint8_t* const dirty = ddirty.as<uint8_t>();
   uint8_t* const touched = dirty + nchunk;
   const dim3 cgrid((unsigned)((nchunk + 255) / 256)), cgrid1((unsigned)((nchunk + 1 + 255) / 256)), blk(256);
-  hipLaunchKernelGGL(init_states_kernel, cgrid1, blk, 0, st, nchunk, dentry.as<ChunkState>(), dexit.as<ChunkState>(),
-                     dnb.as<uint64_t>(), dirty, touched);
-  OGD_TRY(check_launch("init_states_kernel"));
   const DecTables* tabs = dtabs.as<DecTables>();
   const bool multi = info.tabs.bpm > 1;
   const bool rst = info.restart > 0 && !info.rst.empty();  // a DRI file of one interval is an ordinary scan
+  DevBuf dper;  // period of the bit string around each chunk (blank paper), for the state passes
+  {
+    OGD_TRY(dper.alloc((size_t)nchunk + 16));
+    hipLaunchKernelGGL(period_kernel, dim3((unsigned)((nchunk + 16 + 255) / 256)), blk, 0, st, dstream.as<uint8_t>(),
+                       total_bits, nchunk, dper.as<uint8_t>());
+    OGD_TRY(check_launch("period_kernel"));
+  }
+  hipLaunchKernelGGL(init_states_kernel, cgrid1, blk, 0, st, nchunk, dentry.as<ChunkState>(), dexit.as<ChunkState>(),
+                     dnb.as<uint64_t>(), dirty, touched, dper.as<uint8_t>());
+  OGD_TRY(check_launch("init_states_kernel"));
   const auto state_pass = multi ? (rst ? &decode_chunks_kernel<false, true, true> : &decode_chunks_kernel<false, true, false>)
                                 : (rst ? &decode_chunks_kernel<false, false, true> : &decode_chunks_kernel<false, false, false>);
   const auto write_pass = multi ? (rst ? &decode_chunks_kernel<true, true, true> : &decode_chunks_kernel<true, true, false>)
@@ -964,7 +1084,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
                        dentry.as<ChunkState>(), dexit.as<ChunkState>(), dnb.as<uint64_t>(), dflag.as<int>(),
                        (const uint64_t*)nullptr, nmcu, (int16_t*)nullptr, (int32_t*)nullptr,
                        rounds < 3 ? 0 : std::min(2048 * (1024 / CHUNK_BITS), (4 * (1024 / CHUNK_BITS)) << std::min(rounds - 3, 12)), rst_bits, nrst, info.restart,
-                       (int*)nullptr, dirty, touched);
+                       (int*)nullptr, dirty, touched, dper.as<uint8_t>());
     OGD_TRY(check_launch("decode_chunks_kernel"));
     int changed = 0;
     OGD_HIP(hipMemcpyAsync(&changed, dflag.p, sizeof changed, hipMemcpyDeviceToHost, st));
@@ -983,6 +1103,19 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
     hipLaunchKernelGGL(shift_states_kernel, cgrid, blk, 0, st, dexit.as<ChunkState>(), nchunk, dentry.as<ChunkState>(),
                        dirty, touched);
     OGD_TRY(check_launch("shift_states_kernel"));
+    if (std::getenv("OGD_JPEG_DEBUG") && std::atoi(std::getenv("OGD_JPEG_DEBUG")) > 1) {  // chunks to walk next round
+      std::vector<uint8_t> hd((size_t)nchunk);
+      OGD_HIP(hipMemcpyAsync(hd.data(), dirty, (size_t)nchunk, hipMemcpyDeviceToHost, st));
+      OGD_HIP(hipStreamSynchronize(st));
+      int64_t nd = 0, first = -1, last = -1;
+      for (int64_t c = 0; c < nchunk; ++c)
+        if (hd[(size_t)c]) {
+          ++nd;
+          if (first < 0) first = c;
+          last = c;
+        }
+      fprintf(stderr, "ogd_jpeg_decode: after round %d: %lld chunks to walk (%lld .. %lld)\n", rounds, (long long)nd, (long long)first, (long long)last);
+    }
   }
   // the last round ran from entry = shifted exits of the round before and reproduced them: entry is exact
   if (std::getenv("OGD_JPEG_DEBUG")) fprintf(stderr, "ogd_jpeg_decode: %d chunks settled in %d rounds\n", nchunk, rounds);
@@ -1004,7 +1137,7 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   hipLaunchKernelGGL(write_pass, cgrid, blk, 0, st, dstream.as<uint8_t>(), total_bits, nchunk, tabs,
                      dentry.as<ChunkState>(), (ChunkState*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
                      dnb.as<uint64_t>(), nmcu, dcoef.as<int16_t>(), ddc.as<int32_t>(), 0, rst_bits, nrst, info.restart,
-                     dcheck.as<int>(), (const uint8_t*)nullptr, (uint8_t*)nullptr);
+                     dcheck.as<int>(), (const uint8_t*)nullptr, (uint8_t*)nullptr, (const uint8_t*)nullptr);
   OGD_TRY(check_launch("decode_chunks_kernel<write>"));
   // D5: DC prediction runs per component, in stream order: one inclusive scan per component's slots
   {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """N4 decoder on periodic streams: blank margins, flat images, checkerboards — the cases in which
 chunk walks do not re-synchronise by themselves.  Prints PIL's and the device decoder's time per case; run with
-OGD_JPEG_DEBUG=1 to see the round counts."""
+OGD_JPEG_DEBUG=1 to see the round counts.  Usage: jpeg_hard_cases.py [W H [part of a case name]]"""
 import io
 import sys
 import time
@@ -15,10 +15,16 @@ from origami_amd import _shim, synth  # noqa: E402
 
 _shim.init(0)
 rng = np.random.default_rng(5)
-W, H = 3000, 4000
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3000, 4000)
+print("%d x %d" % (W, H))
+
+
+ONLY = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
 def case(name, img, **params):
+	if ONLY not in name:
+		return
 	b = io.BytesIO()
 	PIL.Image.fromarray(img).save(b, format="JPEG", **params)
 	data = b.getvalue()
