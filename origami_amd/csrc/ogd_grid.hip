@@ -2,12 +2,15 @@
 // sub-sampling (ref: dewarp.py:557-559) and the inverse point map (ref: dewarp.py:561-576).
 //
 // HBM-bound: 8 B written per dense pixel, 8 B read per node (nodes stay in L1/L2: 628 KB at
-// 323 x 243).  Each thread owns two adjacent columns and walks GF_ROWS rows, so the horizontal
+// 323 x 243).  Cells of 8 pixels and more go through grid_fill_lines_kernel (ogd_grid_lines.h: every store a
+// whole 128-byte line of the output); grid_fill_kernel below serves smaller cells.
+// In grid_fill_kernel each thread owns two adjacent columns and walks GF_ROWS rows, so the horizontal
 // taps are computed once per thread and the horizontally-lerped node rows are re-used for the dense
 // rows of the walk that fall into the same node cell; every store is a 16-byte float4 and a wavefront writes
 // 1 KiB of one dense row per instruction.
 #include "ogd_common.h"
 #include "ogd_resize_math.h"
+#include "ogd_grid_lines.h"
 
 namespace ogd {
 
@@ -16,6 +19,7 @@ namespace ogd {
 // two rows or plain stores are faster alone but slow that K2 down by more than they gain.
 constexpr int GF_THREADS = 512;
 constexpr int GF_ROWS = 4;
+constexpr int GL_COLS = 496, GL_ROWS = 8;  // grid_fill_lines_kernel's tile; its rows must not exceed the cell size
 
 typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
@@ -101,6 +105,17 @@ int ogd_grid_fill_rows_dev(const float* d_nodes, int h, int w, int s, float sx, 
   OGD_REQUIRE(y0 >= 0 && nrows >= 0 && (int64_t)y0 + nrows <= Hd, "rows [%d, %d + %d) outside the dense grid (%d rows)", y0, y0, nrows, Hd);
   if (nrows == 0) return OGD_OK;
   OGD_TRY(ensure_device());
+  OGD_REQUIRE(reinterpret_cast<uintptr_t>(d_out) % 8 == 0, "dense grid buffer must be 8-byte aligned");
+  if (s >= GL_ROWS) {
+    // 496 columns x 8 rows per workgroup: measured against 240 .. 2032 columns and 4 .. 24 rows with the K2 that
+    // follows (tools/kbench "lines", profiles/r02/m_kbench_k1a_lines.log)
+    dim3 lgrid((Wd + 15 + GL_COLS - 1) / GL_COLS, (nrows + GL_ROWS - 1) / GL_ROWS);
+    OGD_REQUIRE(lgrid.y <= 65535u, "dense grid too tall");
+    hipLaunchKernelGGL((grid_fill_lines_kernel<GL_COLS, GL_ROWS, true>), lgrid, dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy,
+                       reinterpret_cast<float2*>(d_out), y0, y0 + nrows, Wd);
+    return check_launch("grid_fill_lines_kernel");
+  }
   dim3 grid((Wd + 2 * GF_THREADS - 1) / (2 * GF_THREADS), (nrows + GF_ROWS - 1) / GF_ROWS);
   OGD_REQUIRE(grid.y <= 65535u, "dense grid too tall");
   hipLaunchKernelGGL(grid_fill_kernel, grid, dim3(GF_THREADS), 0, as_stream(stream),

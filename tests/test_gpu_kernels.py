@@ -25,7 +25,8 @@ def _nodes(rng, h, w, s, amp=6.0):
 
 # ---- K1a ----------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("h,w,s", [(12, 9, 8), (12, 9, 25), (1, 1, 5), (2, 7, 1), (40, 33, 25), (5, 300, 7)])
+@pytest.mark.parametrize("h,w,s", [(12, 9, 8), (12, 9, 25), (1, 1, 5), (2, 7, 1), (40, 33, 25), (5, 300, 7),
+	(1, 1, 8), (3, 1, 9), (1, 40, 9), (7, 131, 9), (100, 41, 8), (9, 62, 8), (4, 63, 16), (30, 3, 31)])
 def test_grid_fill_bit_exact(gpu, h, w, s):
 	rng = np.random.default_rng(h * 1000 + w * 10 + s)
 	nodes = _nodes(rng, h, w, s)
@@ -33,6 +34,36 @@ def test_grid_fill_bit_exact(gpu, h, w, s):
 	want = ocv.dense_grid(nodes, s)
 	assert got.shape == (h * s, w * s, 2)
 	np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("cell", [7, 8, 25])
+def test_grid_fill_rows_into_any_8_byte_aligned_buffer(gpu, cell):
+	"""ogd_grid_fill_rows_dev: a band of rows written to wherever the caller points (K1a's spans begin on the
+	128-byte lines of the actual address: a buffer 8, 24 or 120 bytes past a line must give the same values)."""
+	import ctypes
+	lib = gpu.load()
+	rng = np.random.default_rng(cell)
+	h, w = 9, 47
+	nodes = _nodes(rng, h, w, cell)
+	want = ocv.dense_grid(nodes, cell)
+	Hd, Wd = want.shape[:2]
+	d_nodes, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_nodes), nodes.nbytes))
+	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_out), want.nbytes + 256))
+	try:
+		gpu.check(lib.ogd_memcpy_h2d(d_nodes, nodes.ctypes.data, nodes.nbytes, None))
+		for shift, y0, n in ((8, 0, Hd), (24, 3, Hd - 3), (120, cell * 4 + 1, 11), (0, Hd - 1, 1)):
+			got = np.full((n, Wd, 2), np.nan, np.float32)
+			gpu.check(lib.ogd_memcpy_h2d(d_out.value + shift, got.ctypes.data, got.nbytes, None))
+			gpu.check(lib.ogd_grid_fill_rows_dev(d_nodes, h, w, cell, 1.0, 1.0, y0, n, d_out.value + shift, None))
+			gpu.check(lib.ogd_memcpy_d2h(got.ctypes.data, d_out.value + shift, got.nbytes, None))
+			gpu.check(lib.ogd_stream_sync(None))
+			np.testing.assert_array_equal(got, want[y0:y0 + n])
+		with pytest.raises(gpu.OgdError):
+			gpu.check(lib.ogd_grid_fill_rows_dev(d_nodes, h, w, cell, 1.0, 1.0, 0, 1, d_out.value + 4, None))
+	finally:
+		lib.ogd_dev_free(d_nodes)
+		lib.ogd_dev_free(d_out)
 
 
 def test_grid_fill_scaled_copy(gpu):

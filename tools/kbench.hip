@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void map_stream_tile(const float* __restrict__
 
 // K1a lab: store policy, rows per thread and block width of the grid fill (copy of grid_fill_kernel's loop)
 #include "../origami_amd/csrc/ogd_resize_math.h"
+#include "../origami_amd/csrc/ogd_grid_lines.h"
 template <int NT, int ROWS, int THREADS>
 __global__ __launch_bounds__(THREADS) void grid_fill_variant(const float2* __restrict__ nodes, int h, int w,
                                                              double inv_s, float2* __restrict__ out, int Hd, int Wd,
@@ -217,6 +218,19 @@ struct Ctx {
   float* map;
   std::vector<uint8_t> h_ref, h_out;
 };
+
+// store ceiling: the map's bytes written as fully aligned float4, nothing computed
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_only(float4* __restrict__ out4, size_t n4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4* __restrict__ out = reinterpret_cast<f4*>(out4);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f4 v = {(float)i, 1.f, 2.f, 3.f};
+    if (NT) __builtin_nontemporal_store(v, out + i);
+    else out[i] = v;
+  }
+}
 
 template <class F>
 static void run(Ctx& c, const char* name, F launch, bool check = true) {
@@ -380,6 +394,39 @@ int main(int argc, char** argv) {
   K1A_VARIANT(1, 2, 1024)
   K1A_VARIANT(1, 1, 1024)
   K1A_VARIANT(0, 4, 1024)
+  for (int blocks : {2048, 8192, 65536}) {
+    char name[64];
+    snprintf(name, sizeof name, "K1a alone pure fill nt=1 blocks=%d", blocks);
+    run(c, name, [&] { hipLaunchKernelGGL(fill_only<true>, dim3(blocks), dim3(256), 0, 0, (float4*)c.map, (size_t)c.Hd * c.Wd / 2); }, false);
+    snprintf(name, sizeof name, "K1a alone pure fill nt=0 blocks=%d", blocks);
+    run(c, name, [&] { hipLaunchKernelGGL(fill_only<false>, dim3(blocks), dim3(256), 0, 0, (float4*)c.map, (size_t)c.Hd * c.Wd / 2); }, false);
+  }
+#define LINES_VARIANT(TW, TR, NT)                                                                       \
+  {                                                                                                       \
+    auto k1a = [&] {                                                                                      \
+      hipLaunchKernelGGL((grid_fill_lines_kernel<TW, TR, NT>), dim3((c.Wd + 15 + TW - 1) / TW, (c.Hd + TR - 1) / TR), \
+                         dim3(256), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, (float2*)c.map, 0, \
+                         c.Hd, c.Wd);                                                                     \
+    };                                                                                                    \
+    run(c, "K1a alone lines TW=" #TW " TR=" #TR " nt=" #NT, k1a, false);                                  \
+    run(c, "K1a+K2    lines TW=" #TW " TR=" #TR " nt=" #NT, [&] { k1a(); lib(); });                       \
+  }
+  LINES_VARIANT(1008, 4, true)
+  LINES_VARIANT(1008, 8, true)
+  LINES_VARIANT(1008, 8, false)
+  LINES_VARIANT(1008, 12, true)
+  LINES_VARIANT(1008, 16, true)
+  LINES_VARIANT(496, 8, true)
+  LINES_VARIANT(496, 16, true)
+  LINES_VARIANT(2032, 8, true)
+  LINES_VARIANT(240, 8, true)
+  LINES_VARIANT(240, 16, true)
+  LINES_VARIANT(240, 24, true)
+  LINES_VARIANT(496, 4, true)
+  LINES_VARIANT(496, 6, true)
+  LINES_VARIANT(496, 10, true)
+  LINES_VARIANT(496, 12, true)
+  LINES_VARIANT(752, 8, true)
   run(c, "library K1a alone", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); }, false);
   run(c, "library K1a + K2", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); lib(); });
 
