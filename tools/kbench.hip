@@ -232,6 +232,19 @@ __global__ __launch_bounds__(256) void fill_only(float4* __restrict__ out4, size
   }
 }
 
+// block b writes the contiguous chunk [b * per, (b + 1) * per) float4, its threads side by side
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_chunked(float4* __restrict__ out4, size_t n4, size_t per) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4* __restrict__ out = reinterpret_cast<f4*>(out4);
+  const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
+  for (size_t i = b0 + threadIdx.x; i < b1; i += 256) {
+    const f4 v = {(float)i, 1.f, 2.f, 3.f};
+    if (NT) __builtin_nontemporal_store(v, out + i);
+    else out[i] = v;
+  }
+}
+
 template <class F>
 static void run(Ctx& c, const char* name, F launch, bool check = true) {
   if (const char* only = getenv("KB_ONLY"))
@@ -401,32 +414,39 @@ int main(int argc, char** argv) {
     snprintf(name, sizeof name, "K1a alone pure fill nt=0 blocks=%d", blocks);
     run(c, name, [&] { hipLaunchKernelGGL(fill_only<false>, dim3(blocks), dim3(256), 0, 0, (float4*)c.map, (size_t)c.Hd * c.Wd / 2); }, false);
   }
-#define LINES_VARIANT(TW, TR, NT)                                                                       \
+#define LINES_VARIANT(TW, TR, NTH)                                                                      \
   {                                                                                                       \
     auto k1a = [&] {                                                                                      \
-      hipLaunchKernelGGL((grid_fill_lines_kernel<TW, TR, NT>), dim3((c.Wd + 15 + TW - 1) / TW, (c.Hd + TR - 1) / TR), \
-                         dim3(256), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, (float2*)c.map, 0, \
+      hipLaunchKernelGGL((grid_fill_lines_kernel<TW, TR, true, NTH>), dim3((c.Wd + 15 + TW - 1) / TW, (c.Hd + TR - 1) / TR), \
+                         dim3(NTH), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, (float2*)c.map, 0, \
                          c.Hd, c.Wd);                                                                     \
     };                                                                                                    \
-    run(c, "K1a alone lines TW=" #TW " TR=" #TR " nt=" #NT, k1a, false);                                  \
-    run(c, "K1a+K2    lines TW=" #TW " TR=" #TR " nt=" #NT, [&] { k1a(); lib(); });                       \
+    run(c, "K1a alone lines TW=" #TW " TR=" #TR " threads=" #NTH, k1a, false);                            \
+    run(c, "K1a+K2    lines TW=" #TW " TR=" #TR " threads=" #NTH, [&] { k1a(); lib(); });                 \
   }
-  LINES_VARIANT(1008, 4, true)
-  LINES_VARIANT(1008, 8, true)
-  LINES_VARIANT(1008, 8, false)
-  LINES_VARIANT(1008, 12, true)
-  LINES_VARIANT(1008, 16, true)
-  LINES_VARIANT(496, 8, true)
-  LINES_VARIANT(496, 16, true)
-  LINES_VARIANT(2032, 8, true)
-  LINES_VARIANT(240, 8, true)
-  LINES_VARIANT(240, 16, true)
-  LINES_VARIANT(240, 24, true)
-  LINES_VARIANT(496, 4, true)
-  LINES_VARIANT(496, 6, true)
-  LINES_VARIANT(496, 10, true)
-  LINES_VARIANT(496, 12, true)
-  LINES_VARIANT(752, 8, true)
+  LINES_VARIANT(496, 8, 256)
+  LINES_VARIANT(496, 8, 512)
+  LINES_VARIANT(496, 8, 1024)
+  LINES_VARIANT(496, 4, 1024)
+  LINES_VARIANT(496, 4, 512)
+  LINES_VARIANT(496, 2, 512)
+  LINES_VARIANT(496, 12, 768)
+  LINES_VARIANT(496, 16, 1024)
+  LINES_VARIANT(240, 8, 1024)
+  LINES_VARIANT(240, 8, 512)
+  LINES_VARIANT(368, 8, 1024)
+  LINES_VARIANT(512, 8, 1024)
+  for (int kb : {4, 8, 16, 32, 64, 256, 1024}) {
+    char name[64];
+    const size_t n4 = (size_t)c.Hd * c.Wd / 2, per = (size_t)kb * 1024 / 16;
+    snprintf(name, sizeof name, "K1a alone chunk fill nt=1 %d KB per block", kb);
+    run(c, name, [&] { hipLaunchKernelGGL(fill_chunked<true>, dim3((unsigned)((n4 + per - 1) / per)), dim3(256), 0, 0, (float4*)c.map, n4, per); }, false);
+  }
+  for (int blocks : {16384, 32768, 65536, 95800}) {
+    char name[64];
+    snprintf(name, sizeof name, "K1a alone pure fill nt=1 blocks=%d", blocks);
+    run(c, name, [&] { hipLaunchKernelGGL(fill_only<true>, dim3(blocks), dim3(256), 0, 0, (float4*)c.map, (size_t)c.Hd * c.Wd / 2); }, false);
+  }
   run(c, "library K1a alone", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); }, false);
   run(c, "library K1a + K2", [&] { OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr)); lib(); });
 
