@@ -34,6 +34,9 @@
 #include <chrono>
 #include <cstring>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace ogd {
 namespace {
@@ -879,6 +882,30 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, bool headers_o
   size_t e = p;
   uint64_t nstuff = 0;  // stuffed zero bytes so far
   while (true) {
+    // 64 bytes at a time while they hold nothing but data and stuffed zeros (a scan has a 0xFF every ~50 bytes:
+    // one memchr call per 0xFF made this walk 2 ms of a broadsheet page's 3); the two reductions vectorise
+    while (e + 65 <= n) {
+      unsigned marker = 0, stuffed = 0;
+#if defined(__SSE2__)
+      const __m128i all_ff = _mm_set1_epi8((char)0xFF), all_0 = _mm_setzero_si128();
+      for (int i = 0; i < 64; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(f + e + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(f + e + i + 1));
+        const __m128i is_ff = _mm_cmpeq_epi8(a, all_ff), zero_next = _mm_cmpeq_epi8(b, all_0);
+        marker |= (unsigned)_mm_movemask_epi8(_mm_andnot_si128(zero_next, is_ff));
+        stuffed += (unsigned)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_and_si128(is_ff, zero_next)));
+      }
+#else
+      for (int i = 0; i < 64; ++i) {
+        const unsigned is_ff = f[e + i] == 0xFF, zero_next = f[e + i + 1] == 0x00;
+        marker |= is_ff & (zero_next ^ 1u);
+        stuffed += is_ff & zero_next;
+      }
+#endif
+      if (marker) break;
+      nstuff += stuffed;
+      e += 64;
+    }
     const uint8_t* ff = (const uint8_t*)std::memchr(f + e, 0xFF, n - e);
     OGD_REQUIRE(ff && (size_t)(ff - f) + 1 < n, "JPEG scan is not terminated by a marker");
     e = (size_t)(ff - f);
