@@ -7,41 +7,35 @@ its dewarping transform (ref: origami/batch/core/io.py:275-280, origami/core/pag
 goes through the fused grid-fill + remap kernel and the device-side JPEG encoder (ogd_dewarp_jpeg_gray): the
 file is the one PIL writes for `page.dewarped`, byte for byte, and only its ~0.14 B/px cross PCIe."""
 
-from pathlib import Path
-
 import click
 
-from ..core.io import Annotation, Artifact, Input, Output, Stage
+from ..core import io
 from ..core.processor import Processor
 
 
 class DewarpProcessor(Processor):
+	# runtime.json key: the reference's __loader__.name for this stage
+	processor_name = "origami.batch.utils.dewarp"
+
 	def __init__(self, options):
 		super().__init__(options)
 		self._options = dict(options)
 
-	@property
-	def processor_name(self):
-		return "origami.batch.utils.dewarp"  # the reference's __loader__.name (runtime.json key)
-
 	def artifacts(self):
-		return [
-			("dewarped", Input(Artifact.DEWARPING_TRANSFORM, stage=Stage.DEWARPED)),
-			("output", Output(Annotation("dewarped"))),
-		]
+		"""Reads dewarp.zip (through the page it opens), writes the annotation image "dewarped"."""
+		source = io.Input(io.Artifact.DEWARPING_TRANSFORM, stage=io.Stage.DEWARPED)
+		return [("dewarped", source), ("output", io.Output(io.Annotation("dewarped")))]
 
-	def process(self, page_path: Path, dewarped, output):
-		# the reference saves the PIL image dewarped.page.dewarped; the same file comes encoded from the device
+	def process(self, page_path, dewarped, output):
+		# the reference saves the PIL image `dewarped.page.dewarped`; the same file comes encoded from the device
 		output.annotation(dewarped.page.dewarped_jpeg())
 
 
-@click.command()
-@click.argument('data_path', type=click.Path(exists=True), required=True)
+@click.command(help="Create dewarped images for all document images in DATA_PATH.")
+@click.argument("data_path", type=click.Path(exists=True), required=True)
 @Processor.options
-def dewarp(data_path, **kwargs):
-	""" Create dewarped images for all document images in DATA_PATH. """
-	processor = DewarpProcessor(kwargs)
-	processor.traverse(data_path)
+def dewarp(data_path, **options):
+	DewarpProcessor(options).traverse(data_path)
 
 
 if __name__ == "__main__":

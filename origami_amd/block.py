@@ -30,143 +30,124 @@ def _cut_baseline(p0, p1, x, default):
 	return np.array([x, ay + t * (by - ay)])
 
 
+def _evidence(confidence):
+	"""[(label path string, value)] of a line's per-label confidences without the BACKGROUND entries;
+	None if the confidence is a plain number (block.py:63-102 repeat this filter three times)."""
+	if not isinstance(confidence, dict):
+		return None
+	return [(key, value) for key, value in confidence.items() if not key.endswith("/BACKGROUND")]
+
+
 class Line:
-	"""ref: block.py:35-333 — geometry (p, right, up), confidence and the dewarped image."""
+	"""ref: block.py:35-333 — a text line in dewarped coordinates: origin `p`, baseline vector `right`, height
+	vector `up`; confidence (a number, or a dict label path -> evidence from ConfidenceSampler); the dewarped
+	image."""
 
 	def __init__(self, block, p, right, up, tesseract_data=None, wkt=None, text_area=None, confidence=1):
-		self._tesseract_data = tesseract_data
 		self._block = block
-		self._p = np.array(p)
-		self._right = np.array(right)
-		self._up = np.array(up)
-		self._wkt = wkt
+		self._p, self._right, self._up = (np.array(v) for v in (p, right, up))
+		self._wkt, self._tesseract_data = wkt, tesseract_data
 		self._confidence = confidence
 
-	@property
-	def block(self):
-		return self._block
-
-	@property
-	def angle(self):
-		return math.atan2(self._right[1], self._right[0])
+	block = property(lambda self: self._block)
+	angle = property(lambda self: math.atan2(self._right[1], self._right[0]))
+	length = property(lambda self: np.linalg.norm(self._right))
+	height = property(lambda self: np.linalg.norm(self._up))
 
 	@property
 	def confidence(self):
-		if not isinstance(self._confidence, dict):
+		found = _evidence(self._confidence)
+		if found is None:
 			return self._confidence
-		values = [v for k, v in self._confidence.items() if not k.endswith("/BACKGROUND")]
-		return max(values) if values else 0
+		return max((value for _, value in found), default=0)
+
+	def _best_label(self):
+		"""(label path tuple, evidence) of the strongest non-background label (the first of equals), or None."""
+		found = _evidence(self._confidence)
+		if not found:
+			return None
+		key, value = found[int(np.argmax([v for _, v in found]))]
+		return tuple(key.split("/")), value
 
 	@property
 	def predicted_path(self):
-		if not isinstance(self._confidence, dict):
-			return None
-		items = [(k, v) for k, v in self._confidence.items() if not k.endswith("/BACKGROUND")]
-		if items:
-			return tuple(items[int(np.argmax([x[1] for x in items]))][0].split("/"))
-		return None
+		best = self._best_label()
+		return best[0] if best else None
 
 	def predicted_path_error(self, path):
-		# block.py:91-102
-		if not isinstance(self._confidence, dict):
+		"""How much more evidence the strongest label has than `path` (block.py:91-102); 0 if they agree."""
+		best = self._best_label()
+		if best is None or best[0] == path:
 			return 0
-		items = [(k, v) for k, v in self._confidence.items() if not k.endswith("/BACKGROUND")]
-		if items:
-			i = int(np.argmax([x[1] for x in items]))
-			if tuple(items[i][0].split("/")) == path:
-				return 0
-			return items[i][1] - self._confidence.get("/".join(path), 0)
-		return 0
+		return best[1] - self._confidence.get("/".join(path), 0)
 
 	def update_confidence(self, confidence):
 		self._confidence = confidence
 
 	@property
-	def length(self):
-		return np.linalg.norm(self._right)
-
-	@property
-	def height(self):
-		return np.linalg.norm(self._up)
-
-	@property
 	def info(self):
-		return dict(
-			p=self._p.tolist(), right=self._right.tolist(), up=self._up.tolist(), wkt=self._wkt,
-			confidence=self._confidence, tesseract_data=self._tesseract_data)
+		# key order as the reference writes it (lines are stored as JSON)
+		record = {name: getattr(self, "_" + name).tolist() for name in ("p", "right", "up")}
+		for name in ("wkt", "confidence", "tesseract_data"):
+			record[name] = getattr(self, "_" + name)
+		return record
 
 	def _position(self, xres, column):
-		# block.py:195-221
-		p0, right, up = self._p, self._right, self._up
-		if column is not None:
-			p1 = p0 + right
-			px0, px1 = min(p0[0], p1[0]), max(p0[0], p1[0])
-			x0, x1 = column
-			if x0 is None:
-				x0 = px0
-			if x1 is None:
-				x1 = px1
-			q0 = _cut_baseline(p0, p1, x0, default=p0)
-			q1 = _cut_baseline(p0, p1, x1, default=p1)
-			p0, p1 = q0, q1
-			right = p1 - p0
-			xres *= (x1 - x0) / (px1 - px0)
-		return p0, right, up, xres
+		"""(origin, right, up, xres) of the line, or of its part between the abscissae column = (x0, x1), either
+		of which may be None for "the line's own end" (block.py:195-221)."""
+		origin, right = self._p, self._right
+		if column is None:
+			return origin, right, self._up, xres
+		end = origin + right
+		lo, hi = sorted((origin[0], end[0]))
+		x0, x1 = (own if asked is None else asked for asked, own in zip(column, (lo, hi)))
+		cut0 = _cut_baseline(origin, end, x0, default=origin)
+		cut1 = _cut_baseline(origin, end, x1, default=end)
+		return cut0, cut1 - cut0, self._up, xres * ((x1 - x0) / (hi - lo))
 
 	def _steps(self, rough, xsteps, ysteps, xres, yres):
-		# block.py:230-236; rough: (2, 2, 2) warped positions of the lattice corners
-		if xsteps is None:
-			xsteps = np.max(np.abs(rough[:, 0, 0] - rough[:, 1, 0]))
-			xsteps = max(2, int(np.ceil(xsteps * xres)))
-		if ysteps is None:
-			ysteps = np.max(np.abs(rough[0, :, 1] - rough[1, :, 1]))
-			ysteps = max(2, int(np.ceil(ysteps * yres)))
-		return xsteps, ysteps
+		"""Lattice size from the warped positions `rough` (2, 2, 2) of the line's corners: the longer of the two
+		edges per direction times the resolution, at least 2 (block.py:230-236)."""
+		def count(given, extent, res):
+			return given if given is not None else max(2, int(np.ceil(extent * res)))
+		return (count(xsteps, np.max(np.abs(rough[:, 0, 0] - rough[:, 1, 0])), xres),
+			count(ysteps, np.max(np.abs(rough[0, :, 1] - rough[1, :, 1])), yres))
 
 	def warped_grid(self, xsteps=None, ysteps=None, xres=1, yres=1, column=None):
 		"""(ysteps, xsteps, 2) float32 positions (x, y) on the warped page.  ref: block.py:223-248."""
-		p0, right, up, xres = self._position(xres, column)
+		origin, right, up, xres = self._position(xres, column)
 		if xsteps is None or ysteps is None:
-			rough = self.warped_grid(xsteps=2, ysteps=2)
-			xsteps, ysteps = self._steps(rough, xsteps, ysteps, xres, yres)
-		ys = np.linspace([0, 0], up, ysteps)
-		xs = np.linspace([0, 0], right, xsteps)
-		dewarped_grid = (ys + p0)[:, np.newaxis] + xs[np.newaxis, :]
-		dewarped_grid = np.flip(dewarped_grid, axis=-1)
-		inv = self.block.page.dewarper.grid.inverse_yx
-		warped_grid = inv(dewarped_grid.reshape((len(ys) * len(xs), 2)))
-		return warped_grid.reshape((len(ys), len(xs), 2)).astype(np.float32)
+			xsteps, ysteps = self._steps(self.warped_grid(xsteps=2, ysteps=2), xsteps, ysteps, xres, yres)
+		rows = origin + np.linspace([0, 0], up, ysteps)
+		columns = np.linspace([0, 0], right, xsteps)
+		lattice_yx = (rows[:, None] + columns[None, :])[..., ::-1]
+		warped = self.block.page.dewarper.grid.inverse_yx(lattice_yx.reshape(-1, 2))
+		return warped.reshape(ysteps, xsteps, 2).astype(np.float32)
 
 	def dewarped_image(self, target_height=48, column=None, interpolation=INTER_LINEAR):
 		"""ref: block.py:250-259."""
 		assert self.block.stage.is_dewarped
-		return dewarped_line_images(
-			self.block.page, [(self, column)], target_height, interpolation)[0]
+		return dewarped_line_images(self.block.page, [(self, column)], target_height, interpolation)[0]
 
 	def image(self, target_height=48, column=None, dewarped=True, deskewed=True, binarizer=None):
-		# block.py:129-143
+		"""ref: block.py:129-143; only the dewarped variant is built."""
 		if not dewarped:
 			raise NotImplementedError("only dewarped line images are produced on the GPU")
 		im = self.dewarped_image(target_height, column=column)
-		if binarizer:
-			im = binarizer(im)
-		return im
+		return binarizer(im) if binarizer else im
 
 	def warped_path(self, resolution=1):
-		# block.py:261-267
+		"""(centre line on the warped page, median height).  ref: block.py:261-267."""
 		assert self.block.stage.is_dewarped
-		warped_grid = self.warped_grid(ysteps=2, xres=resolution)
-		height = np.median(np.linalg.norm(warped_grid[1] - warped_grid[0], axis=-1))
-		return np.mean(warped_grid, axis=0), abs(height)
+		lower, upper = self.warped_grid(ysteps=2, xres=resolution)
+		return (lower + upper) / 2, abs(np.median(np.linalg.norm(upper - lower, axis=-1)))
 
 	def dewarped_height(self, dewarper):
-		# block.py:326-333
+		"""Height of a line given in WARPED coordinates once it is dewarped.  ref: block.py:326-333."""
 		assert not self._block.stage.is_dewarped
-		p0, up = self._p, self._up
-		p1 = p0 + up
-		tx, ty = dewarper.grid.transformer(*np.array([p0, p1]).transpose())
-		q0, q1 = np.array([tx, ty]).transpose()
-		return np.linalg.norm(q1 - q0)
+		ends = np.array([self._p, self._p + self._up])
+		tx, ty = dewarper.grid.transformer(ends[:, 0], ends[:, 1])
+		return np.linalg.norm(np.array([tx[1] - tx[0], ty[1] - ty[0]]))
 
 
 class Block:
@@ -176,22 +157,14 @@ class Block:
 
 	def __init__(self, page, polygon, stage):
 		self._page = page
-		self._polygon = polygon
-		self._stage = stage
+		self.image_space_polygon = polygon
+		self.stage = stage
 
 	@property
 	def page(self):
 		if callable(self._page):
 			self._page = self._page()
 		return self._page
-
-	@property
-	def image_space_polygon(self):
-		return self._polygon
-
-	@property
-	def stage(self):
-		return self._stage
 
 
 def line_lattices(grid, items, target_height=None, xres=1, yres=1):

@@ -1,6 +1,8 @@
 """Reading `segment.zip`: label maps and their classes (ref: origami/core/segment.py:17-67,
-origami/core/predict.py:136-146, 371-397).  Only what ConfidenceSampler needs."""
+origami/core/predict.py:136-146, 371-397).  Only what ConfidenceSampler needs: per predictor a palette PNG
+`<name>.png` with the labels and `<name>.json` with {"type", "name", "classes"}."""
 
+import collections
 import enum
 import io
 import json
@@ -11,61 +13,38 @@ import PIL.Image
 
 from .batch.core.io import PredictorType
 
+_LABEL_ENUMS = {PredictorType.REGION: "RegionLabel", PredictorType.SEPARATOR: "SeparatorLabel"}
 
-class Prediction:
-	def __init__(self, type, name, labels, classes):
-		self._type = type
-		self._name = name
-		self._labels = labels
-		self._classes = classes
-		self._background = self._classes["BACKGROUND"]
 
-	@property
-	def type(self):
-		return self._type
-
-	@property
-	def name(self):
-		return self._name
+class Prediction(collections.namedtuple("Prediction", "type name labels classes")):
+	"""One predictor's label map: `labels` (h, w) uint8, `classes` the Enum of its label values."""
+	__slots__ = ()
 
 	@property
 	def background_label(self):
-		return self._background
+		return self.classes["BACKGROUND"]
 
-	@property
-	def labels(self):
-		return self._labels
 
-	@property
-	def classes(self):
-		return self._classes
+def _read_prediction(zf, stem):
+	meta = json.loads(zf.read(stem + ".json"))
+	kind = PredictorType[meta["type"]]
+	with PIL.Image.open(io.BytesIO(zf.read(stem + ".png"))) as im:
+		labels = np.array(im)
+	return Prediction(kind, meta["name"], labels, enum.Enum(_LABEL_ENUMS[kind], meta["classes"]))
 
 
 class Segmentation:
 	def __init__(self, predictions):
-		self._predictions = tuple(predictions)
-
-	@property
-	def predictions(self):
-		return self._predictions
+		self.predictions = tuple(predictions)
 
 	@property
 	def size(self):
-		shape = self._predictions[0].labels.shape
-		return tuple(reversed(list(shape)[:2]))
+		"""(width, height) of the label maps."""
+		h, w = self.predictions[0].labels.shape[:2]
+		return (w, h)
 
 	@staticmethod
 	def open(path):
-		predictions = []
 		with zipfile.ZipFile(path, "r") as zf:
-			tasks = [name.rsplit(".", 1)[0] for name in zf.namelist() if name.endswith(".png")]
-			for task in tasks:
-				with io.BytesIO(zf.read(task + ".png")) as f:
-					im = PIL.Image.open(f)
-					im.load()
-				meta = json.loads(zf.read(task + ".json"))
-				t = PredictorType[meta["type"]]
-				label_enum = "RegionLabel" if t == PredictorType.REGION else "SeparatorLabel"
-				classes = enum.Enum(label_enum, meta["classes"])
-				predictions.append(Prediction(t, meta["name"], np.array(im), classes))
-		return Segmentation(predictions)
+			stems = [n[:-len(".png")] for n in zf.namelist() if n.endswith(".png")]
+			return Segmentation(_read_prediction(zf, s) for s in stems)
