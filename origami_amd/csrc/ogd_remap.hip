@@ -46,7 +46,7 @@ static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, 
   constexpr int TW = 4 * LX, TH = (64 / LX) * RPT;
   constexpr int LDSW = C == 1 ? 4096 : TileShape<MapSrc>::LDSW_MC;  // source window budget per wavefront
   const int nbx = (Wd + TW - 1) / TW, nby = (Hd + TH - 1) / TH, nb = nbx * nby;
-  const dim3 grid((nb + 3) / 4), block(256);
+  const dim3 grid((nb + RL_WPB - 1) / RL_WPB), block(64 * RL_WPB);
   if (interp == OGD_INTER_LINEAR)
     hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, LX, RPT, LDSW, MapSrc>), grid, block,
                        0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);

@@ -267,8 +267,12 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 #define RL_W1B 6
 #endif
 #define RL_WAVES_PER_SIMD(C, RPT) ((C) == 1 ? ((RPT) <= 2 ? 8 : RL_W1B) : 5)
+// Wavefronts per workgroup (neighbouring tiles of one tile row): 4; tools/kbench builds other values to measure
+#ifndef RL_WPB
+#define RL_WPB 4
+#endif
 template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
-__global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
+__global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
     const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
     uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
@@ -282,10 +286,10 @@ __global__ __launch_bounds__(256, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_
   // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
   constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
 
-  __shared__ __attribute__((aligned(16))) uint32_t win_all[4 * WIN_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t win_all[RL_WPB * WIN_DW];
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + wave;
+  const int t = blockIdx.x * RL_WPB + wave;
   if (t >= nb) return;  // wave-uniform
   uint32_t* win = win_all + wave * WIN_DW;
   const int lx4 = (lane % LX) * 4, ly = lane / LX;

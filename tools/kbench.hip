@@ -476,15 +476,15 @@ int main(int argc, char** argv) {
     const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
     const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
     run(c, "wave LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                            \
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobal>), dim3((nb + 3) / 4),    \
-                         dim3(256), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd},  \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobal>), dim3((nb + RL_WPB - 1) / RL_WPB),    \
+                         dim3(64 * RL_WPB), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd},  \
                          c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                                                                    \
     });                                                                                                 \
   }
   {  // nearest sampling through the same map: the memory side of K2 with a fraction of its integer work
     const int nbx2 = (c.Wd + 63) / 64, nby = (c.Hd + 7) / 8, nb = nbx2 * nby;
     run(c, "wave LX=16 RPT=2 nearest", [&] {
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 0, 16, 2, 4096, MapGlobal>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 0, 16, 2, 4096, MapGlobal>), dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0,
                          c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd}, c.Hd, c.Wd, c.dst,
                          (ptrdiff_t)c.Wd, nbx2, nb);
     }, false);
@@ -501,8 +501,8 @@ int main(int argc, char** argv) {
     const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
     const MapNodes mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, c.Hd, c.Wd};                   \
     run(c, "fused LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                           \
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapNodes>), dim3((nb + 3) / 4),     \
-                         dim3(256), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst,       \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapNodes>), dim3((nb + RL_WPB - 1) / RL_WPB),     \
+                         dim3(64 * RL_WPB), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst,       \
                          (ptrdiff_t)c.Wd, nbx2, nb);                                                    \
     });                                                                                                 \
   }
@@ -510,7 +510,7 @@ int main(int argc, char** argv) {
     const int nbx2 = (c.Wd + 31) / 32, nby = (c.Hd + 31) / 32, nb = nbx2 * nby;
     const MapNodes mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.0000001f, 1.0000001f, c.Hd, c.Wd};
     run(c, "fused LX=8 RPT=4 scaled map", [&] {
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodes>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodes>), dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0,
                          c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);
     }, false);
   }
@@ -518,7 +518,7 @@ int main(int argc, char** argv) {
     const int nbx2 = (c.Wd + 31) / 32, nby = (c.Hd + 31) / 32, nb = nbx2 * nby;
     const MapNodesUnit mn{(const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, c.Hd, c.Wd};
     run(c, "fused LX=8 RPT=4 unit-scale kernel", [&] {
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodesUnit>), dim3((nb + 3) / 4), dim3(256), 0, 0,
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, 8, 4, 4096, MapNodesUnit>), dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0,
                          c.src, c.H, c.W, (ptrdiff_t)c.W, mn, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);
     });
   }
