@@ -1099,10 +1099,11 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   }
   const uint64_t* rst_bits = drst.as<uint64_t>();
   int rounds = 0;
-  // A stream that is periodic throughout (a flat page, a synthetic pattern) is walked by single lanes, chunk after
-  // chunk: slower than libjpeg on a host core.  Time allowance for the rounds: twice what libjpeg would need for the
-  // whole file (~1 ns per sample + 3 ns per scan byte) + 100 ms; past it the file is handed back (a 12 MP 1-pixel
-  // checkerboard would take 2.5 s).
+  // A stream whose period is longer than the lattice steps cover (a synthetic pattern: every block the same ~700
+  // bits) is walked by single lanes, chunk after chunk: slower than libjpeg on a host core.  Time allowance for the
+  // rounds: twice what libjpeg would need for the whole file (~1 ns per sample + 3 ns per scan byte) + 100 ms; past
+  // it the file is handed back (a 12 MP 1-pixel checkerboard would take 2.5 s).  Blank paper does not come here:
+  // its period is a few bits (period_kernel).
   const auto t_rounds = std::chrono::steady_clock::now();
   const double allowance_ms = 100.0 + 2e-6 * (1.0 * (double)H * W * info.ncomp + 3.0 * (double)nscan);
   while (true) {
