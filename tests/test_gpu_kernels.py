@@ -36,6 +36,20 @@ def test_grid_fill_bit_exact(gpu, h, w, s):
 	np.testing.assert_array_equal(got, want)
 
 
+def test_grid_fill_random_shapes(gpu):
+	"""Forty seeded random (h, w, cell) with scales: both K1a kernels (cells below and from 8 pixels), widths that
+	are and are not multiples of the 16-pixel line and of the 496-column tile, heights that end inside a row band."""
+	rng = np.random.default_rng(2024)
+	for _ in range(40):
+		h, w, s = int(rng.integers(1, 40)), int(rng.integers(1, 90)), int(rng.integers(1, 41))
+		nodes = _nodes(rng, h, w, s)
+		sx, sy = (np.float32(1), np.float32(1)) if rng.random() < 0.5 else np.float32(rng.uniform(0.2, 1.5, 2))
+		want = ocv.dense_grid(nodes, s)
+		want[:, :, 0] *= sx
+		want[:, :, 1] *= sy
+		np.testing.assert_array_equal(gpu.grid_fill(nodes, s, sx, sy), want, err_msg="h=%d w=%d cell=%d" % (h, w, s))
+
+
 @pytest.mark.parametrize("cell", [7, 8, 25])
 def test_grid_fill_rows_into_any_8_byte_aligned_buffer(gpu, cell):
 	"""ogd_grid_fill_rows_dev: a band of rows written to wherever the caller points (K1a's spans begin on the
