@@ -301,7 +301,9 @@ def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, streams, slots=3):
 				ev_out[sl].record(s_out)
 		torch.cuda.synchronize()
 
-	run(2 * slots)
+	# Warm-up: one whole cycle over the host ring (the copy engines take some 60 pages to reach their rate:
+	# tools/pipeline_segments.py, profiles/r02/q_pipeline_warmup.log); configs[2] is a queue of 10 000 jobs.
+	run(max(2 * slots, n_pages))
 	barrier()
 	t0 = time.perf_counter()
 	run(n_jobs)

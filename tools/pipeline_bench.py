@@ -2,6 +2,7 @@
 """Throughput (ii) of SURVEY §8d: pinned host -> H2D -> fused dewarp (K1a∘K2) -> D2H, overlapped on three
 streams with a ring of device slots.  PCIe-inclusive; never bench.py's `value`.
 usage: pipeline_bench.py [n_pages slots ring]"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -37,12 +38,27 @@ d_in = torch.empty((slots, H, W), dtype=torch.uint8, device=dev)
 d_out = torch.empty((slots, Hd, Wd), dtype=torch.uint8, device=dev)
 
 s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+if os.environ.get("PIPE_KERNELS_ON_DEFAULT_STREAM"):  # experiment: what bench.py's leg did until round 2
+	s_k = torch.cuda.current_stream()
 ev_in = [torch.cuda.Event() for _ in range(slots)]
 ev_k = [torch.cuda.Event() for _ in range(slots)]
 ev_out = [torch.cuda.Event() for _ in range(slots)]
 
 
+import os
+MODE = os.environ.get("PIPE_MODE", "")  # experiments: "nokernel", "noevents" (copies only, no dependencies)
+
+
 def run(n):
+	if MODE == "noevents":
+		for p in range(n):
+			sl = p % slots
+			with torch.cuda.stream(s_in):
+				d_in[sl].copy_(host_in[p % ring], non_blocking=True)
+			with torch.cuda.stream(s_out):
+				host_out[p % ring].copy_(d_out[sl], non_blocking=True)
+		torch.cuda.synchronize()
+		return
 	for p in range(n):
 		sl = p % slots
 		with torch.cuda.stream(s_in):
@@ -51,9 +67,10 @@ def run(n):
 			ev_in[sl].record(s_in)
 		s_k.wait_event(ev_in[sl])
 		s_k.wait_event(ev_out[sl])  # the slot's previous download has read d_out[sl]
-		check(lib.ogd_dewarp_u8_dev(
-			d_in[sl].data_ptr(), H, W, 1, W, nodes_d.data_ptr(), h, w, CELL, 1.0, 1.0,
-			d_out[sl].data_ptr(), Wd, 1, s_k.cuda_stream))
+		if MODE != "nokernel":
+			check(lib.ogd_dewarp_u8_dev(
+				d_in[sl].data_ptr(), H, W, 1, W, nodes_d.data_ptr(), h, w, CELL, 1.0, 1.0,
+				d_out[sl].data_ptr(), Wd, 1, s_k.cuda_stream))
 		ev_k[sl].record(s_k)
 		with torch.cuda.stream(s_out):
 			s_out.wait_event(ev_k[sl])
@@ -73,6 +90,7 @@ print("pipeline (pinned host in/out, %d slots, fused dewarp): %d pages in %.1f m
 		slots, n_pages, dt * 1e3, dt / n_pages * 1e3, mp / dt, n_pages * H * W / dt / 1e9, n_pages * Hd * Wd / dt / 1e9))
 
 # check the last page against a direct call
-want = _shim.dewarp_u8(host_in[(n_pages - 1) % ring].numpy(), nodes, CELL)
-assert np.array_equal(host_out[(n_pages - 1) % ring].numpy(), want)
-print("last page identical to ogd_dewarp_u8")
+if not MODE:
+	want = _shim.dewarp_u8(host_in[(n_pages - 1) % ring].numpy(), nodes, CELL)
+	assert np.array_equal(host_out[(n_pages - 1) % ring].numpy(), want)
+	print("last page identical to ogd_dewarp_u8")
