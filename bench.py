@@ -277,10 +277,19 @@ def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, streams, slots=3):
 	ev_out = [torch.cuda.Event() for _ in range(slots)]
 	kstream = ctypes.c_void_p(s_k.cuda_stream)
 
+	queued = [False] * slots
+
 	def run(n):
 		for j in range(n):
 			p, sl, ho = j % n_pages, j % slots, j % (slots + 1)
 			wp, poly = wl["warps"][p % len(wl["warps"])], wl["polys"][p]
+			# The host takes delivery of the slot's previous job before it queues the next one (a worker does: it
+			# hands the page on), so at most `slots` jobs are in flight.  With all jobs queued at once the same loop
+			# runs at 2.4 - 5.6 ms/page instead of 1.02: the copies of many queued jobs take turns on the engines
+			# (profiles/r02/q_pipeline_copy_durations.txt shows downloads of 3.8 - 6.9 ms between ones of 1.0).
+			if queued[sl]:
+				ev_out[sl].synchronize()
+			queued[sl] = True
 			with torch.cuda.stream(s_in):
 				s_in.wait_event(ev_k[sl])  # the slot's previous kernel has read d_in[sl]
 				d_in[sl].copy_(host_in[p], non_blocking=True)
@@ -497,7 +506,7 @@ def main():
 		if pipeline is not None:
 			pe = pipeline["elapsed"]
 			line["pipeline"] = {
-				"what": "configs[2] (SURVEY 8d ii): %d page jobs per GPU cycled from a pinned host ring of the batch's %d pages -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + K3 -> D2H of page and contours, 3 streams / 3 device slots per GPU; barrier + max over ranks; PCIe-inclusive, never `value`" % (
+				"what": "configs[2] (SURVEY 8d ii): %d page jobs per GPU cycled from a pinned host ring of the batch's %d pages -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + K3 -> D2H of page and contours, 3 streams / 3 device slots per GPU, at most 3 jobs in flight; barrier + max over ranks; PCIe-inclusive, never `value`" % (
 					pipeline["n_jobs"], args.pages),
 				"value": round(world * pipeline["n_jobs"] * Hd * Wd / 1e6 / pe, 1), "unit": "MP/s",
 				"ms_per_page_per_gpu": round(pe / pipeline["n_jobs"] * 1e3, 4),

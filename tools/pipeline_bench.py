@@ -46,7 +46,7 @@ ev_out = [torch.cuda.Event() for _ in range(slots)]
 
 
 import os
-MODE = os.environ.get("PIPE_MODE", "")  # experiments: "nokernel", "noevents" (copies only, no dependencies)
+MODE = os.environ.get("PIPE_MODE", "")  # experiments: "nokernel", "noevents" (copies only, no dependencies), "deep" (all jobs queued at once)
 
 
 def run(n):
@@ -61,6 +61,8 @@ def run(n):
 		return
 	for p in range(n):
 		sl = p % slots
+		if p >= slots and MODE != "deep":
+			ev_out[sl].synchronize()  # the host takes delivery of the slot's previous page: at most `slots` jobs in flight
 		with torch.cuda.stream(s_in):
 			s_in.wait_event(ev_k[sl])  # the slot's previous kernel has read d_in[sl]
 			d_in[sl].copy_(host_in[p % ring], non_blocking=True)
