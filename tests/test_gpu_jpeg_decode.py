@@ -107,6 +107,36 @@ def test_blank_paper_with_restart_intervals(gpu, restart):
 	_check_file(gpu, _restart_file(np.broadcast_to(np.array((200, 100, 50), np.uint8), (2000, 1504, 3)).copy(), **restart))
 
 
+def test_random_periodic_images(gpu):
+	"""Thirty seeded images that are periodic in parts: a tile of 8 .. 32 pixels repeated over stretches of the page,
+	flat bands, noise in between; random quality, Huffman tables, colour sampling and restart intervals.  Periodic
+	pixels make periodic bit strings of every period the lattice steps do and do not cover; wherever the decoder
+	answers, its pixels are libjpeg's (a file it hands back within its time allowance is none of this test's business)."""
+	rng = np.random.default_rng(77)
+	for case in range(30):
+		h, w = int(rng.integers(200, 900)), int(rng.integers(200, 1200))
+		colour = rng.random() < 0.4
+		img = rng.integers(0, 256, size=(h, w, 3) if colour else (h, w), dtype=np.uint8)
+		for _ in range(int(rng.integers(1, 4))):  # periodic or flat bands over the noise
+			y0, y1 = sorted(int(v) for v in rng.integers(0, h, 2))
+			t = int(rng.choice([8, 16, 24, 32]))
+			tile = rng.integers(0, 256, size=(t, t) + img.shape[2:], dtype=np.uint8)
+			if rng.random() < 0.4:
+				tile[...] = tile[0, 0]
+			reps = (-(-(y1 - y0) // t), -(-w // t)) + (1,) * (img.ndim - 2)
+			img[y0:y1] = np.tile(tile, reps)[:y1 - y0, :w]
+		params = dict(quality=int(rng.choice([30, 60, 75, 90, 100])), optimize=bool(rng.random() < 0.3))
+		if colour:
+			params["subsampling"] = int(rng.integers(0, 3))
+		if rng.random() < 0.3:
+			params["restart_marker_rows"] = int(rng.integers(1, 5))
+			params["optimize"] = False  # PIL's writer cannot do both on large noise images ("broken data stream")
+		data = _colour_file(img, **params)
+		got = gpu.jpeg_decode_gray(data)
+		if got is not None:
+			assert np.array_equal(got, _pil_decode(data)), "case %d: %r %r" % (case, img.shape, params)
+
+
 def test_large_periodic_stream_is_handed_back_in_bounded_time(gpu):
 	"""A 1-pixel checkerboard at quality 100: every block the same ~700 bits, wrong parses are self-consistent and
 	single lanes would walk the whole 5 MB stream (seconds).  The decoder gives up after its time allowance and the
