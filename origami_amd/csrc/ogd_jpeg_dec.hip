@@ -94,16 +94,23 @@ __device__ __forceinline__ bool is_stuffing(const uint8_t* __restrict__ raw, uin
   return b == 0xFFu && i + 1 < n && (raw[i + 1] & 0xF8u) == 0xD0u;
 }
 
+// `markers` (may be null): set to 1 if the segment holds a 0xFF that is not followed by a stuffed zero — a marker, or
+// the segment's last byte.  The host has then taken the end of the scan on trust (PARSE_TRUSTING) and has to look.
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ raw, uint64_t n, int nchunk,
-                                                            uint64_t* __restrict__ counts) {
+                                                            uint64_t* __restrict__ counts, int* __restrict__ markers) {
   typedef hipcub::BlockReduce<int, 256> Reduce;
   __shared__ typename Reduce::TempStorage tmp;
   const int ch = blockIdx.x;
   int c = 0;
   if (ch < nchunk) {
     const uint64_t i0 = (uint64_t)ch * UN_CHUNK + threadIdx.x * 16;
+    bool marker = false;
     for (int k = 0; k < 16; ++k)
-      if (i0 + k < n) c += is_stuffing(raw, i0 + k, n);
+      if (i0 + k < n) {
+        c += is_stuffing(raw, i0 + k, n);
+        marker |= raw[i0 + k] == 0xFF && (i0 + k + 1 >= n || raw[i0 + k + 1] != 0x00);
+      }
+    if (markers != nullptr && marker) *markers = 1;
   }
   const int total = Reduce(tmp).Sum(c);
   if (threadIdx.x == 0) counts[ch] = ch < nchunk ? (uint64_t)total : 0;  // counts[nchunk]: sentinel
@@ -751,6 +758,7 @@ struct JpegInfo {
   const char* why = "";
   size_t scan_begin = 0, scan_end = 0;
   int restart = 0;            // MCUs per restart interval, 0: none
+  bool scan_unchecked = false;  // PARSE_TRUSTING took the scan's end from the file's last two bytes (see parse_jpeg)
   std::vector<uint64_t> rst;  // where intervals 1, 2, ... begin: bit positions in the scan without stuffing and markers
   DecTables tabs;
 };
@@ -761,9 +769,18 @@ struct JpegInfo {
     return OGD_OK;        \
   } while (0)
 
-// Parses the marker segments (headers_only: up to the start of the scan, without walking it).  Returns OGD_ERR_INVALID for something that is not a JPEG file at all; a valid
+// Parses the marker segments.  Returns OGD_ERR_INVALID for something that is not a JPEG file at all; a valid
 // file this decoder does not cover leaves info.supported = false with the reason in info.why.
-static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, bool headers_only = false) {
+//   PARSE_FULL      walks the scan to its end (every 0xFF of it: 0.5 ms for a broadsheet scan);
+//   PARSE_HEADERS   stops at the start of the scan (size and kind are known, nothing said about the scan);
+//   PARSE_TRUSTING  for the decode calls: a file without restart intervals that ends in an EOI marker has its scan
+//                   end there — unless another marker stands inside, which the first device pass finds out while
+//                   it counts the stuffed bytes anyway (info.scan_unchecked; decode_to_device then returns
+//                   SCAN_HAS_MARKERS and the caller parses again with PARSE_FULL).
+enum ParseMode { PARSE_FULL, PARSE_HEADERS, PARSE_TRUSTING };
+constexpr int SCAN_HAS_MARKERS = 1;  // internal, never leaves this file
+static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, ParseMode mode = PARSE_FULL) {
+  const bool headers_only = mode == PARSE_HEADERS;
   OGD_REQUIRE(n >= 4 && f[0] == 0xFF && f[1] == 0xD8, "not a JPEG file (no SOI marker)");
   uint8_t qt[4][64];
   bool have_q[4] = {false, false, false, false};
@@ -881,7 +898,12 @@ static int parse_jpeg(const uint8_t* f, size_t n, JpegInfo& info, bool headers_o
   // the entropy-coded segment ends at the first marker that is not stuffing
   size_t e = p;
   uint64_t nstuff = 0;  // stuffed zero bytes so far
-  while (true) {
+  const bool trusting = mode == PARSE_TRUSTING && restart == 0 && n >= p + 3 && f[n - 2] == 0xFF && f[n - 1] == 0xD9;
+  if (trusting) {
+    e = n - 2;
+    info.scan_unchecked = true;
+  }
+  while (!trusting) {
     // 64 bytes at a time while they hold nothing but data and stuffed zeros (a scan has a 0xFF every ~50 bytes:
     // one memchr call per 0xFF made this walk 2 ms of a broadsheet page's 3); the two reductions vectorise
     while (e + 65 <= n) {
@@ -1047,16 +1069,24 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
   OGD_HIP(hipMemcpyAsync(draw.p, file + info.scan_begin, (size_t)nscan, hipMemcpyHostToDevice, st));
   OGD_HIP(hipMemcpyAsync(dtabs.p, &info.tabs, sizeof(DecTables), hipMemcpyHostToDevice, st));
   OGD_HIP(hipMemsetAsync(dstream.p, 0, (size_t)nscan + 64, st));
+  DevBuf dmarkers;
+  if (info.scan_unchecked) {
+    OGD_TRY(dmarkers.alloc(16));
+    OGD_HIP(hipMemsetAsync(dmarkers.p, 0, 4, st));
+  }
   hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)nun + 1), dim3(256), 0, st, draw.as<uint8_t>(), nscan, nun,
-                     dcnt.as<uint64_t>());
+                     dcnt.as<uint64_t>(), info.scan_unchecked ? dmarkers.as<int>() : (int*)nullptr);
   OGD_TRY(check_launch("unstuff_count_kernel"));
   OGD_TRY(scan_u64(dtmp1, dcnt.as<uint64_t>(), nun + 1, st));
   hipLaunchKernelGGL(unstuff_compact_kernel, dim3((unsigned)nun), dim3(256), 0, st, draw.as<uint8_t>(), nscan,
                      dcnt.as<uint64_t>(), dstream.as<uint8_t>());
   OGD_TRY(check_launch("unstuff_compact_kernel"));
   uint64_t removed = 0;
+  int markers = 0;
   OGD_HIP(hipMemcpyAsync(&removed, dcnt.as<uint64_t>() + nun, sizeof removed, hipMemcpyDeviceToHost, st));
+  if (info.scan_unchecked) OGD_HIP(hipMemcpyAsync(&markers, dmarkers.p, sizeof markers, hipMemcpyDeviceToHost, st));
   OGD_HIP(hipStreamSynchronize(st));
+  if (markers) return SCAN_HAS_MARKERS;  // not an error: the caller parses the file again, walking the scan
   const uint64_t total_bits = (nscan - removed) * 8;
 
   // D2
@@ -1204,15 +1234,35 @@ static int decode_to_device(const uint8_t* file, const JpegInfo& info, uint8_t* 
 }  // namespace
 // For ogd_jpeg_dewarp_jpeg_gray (ogd_jpeg.hip): parse ONCE (finding the end of a broadsheet scan is a walk over
 // every 0xFF of 6 MB, 1.8 ms), then decode into a buffer of the right size.  OGD_ERR_UNSUPPORTED as ogd_jpeg_info says.
+// Parse (trusting the file's end first, see parse_jpeg), check the caller's geometry if it has one (H0 > 0), decode
+// into d_img, or into dimg (allocated here) if d_img is null.
+static int parse_and_decode(const uint8_t* file, size_t n, int H0, int W0, ptrdiff_t stride, uint8_t* d_img, DevBuf* dimg,
+                            int* H, int* W, hipStream_t st) {
+  for (const ParseMode mode : {PARSE_TRUSTING, PARSE_FULL}) {
+    JpegInfo info;
+    OGD_TRY(parse_jpeg(file, n, info, mode));
+    if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
+    if (H0 > 0) {
+      OGD_REQUIRE(H0 == info.H && W0 == info.W, "output is %dx%d, the file holds %dx%d", W0, H0, info.W, info.H);
+      OGD_REQUIRE(stride >= W0, "row stride %td < %d bytes", stride, W0);
+    }
+    OGD_TRY(ensure_device());
+    uint8_t* target = d_img;
+    if (target == nullptr) {
+      OGD_TRY(dimg->alloc((size_t)info.H * info.W));
+      target = dimg->as<uint8_t>();
+      stride = info.W;
+    }
+    if (H) *H = info.H;
+    if (W) *W = info.W;
+    const int status = decode_to_device(file, info, target, stride, st);
+    if (status != SCAN_HAS_MARKERS) return status;
+  }
+  return fail(OGD_ERR_RUNTIME, "JPEG decoder: the scan's markers could not be settled");  // PARSE_FULL never trusts
+}
+
 int jpeg_decode_gray_to(DevBuf& dimg, const uint8_t* file, size_t n, int* H, int* W, void* stream) {
-  JpegInfo info;
-  OGD_TRY(parse_jpeg(file, n, info));
-  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
-  OGD_TRY(ensure_device());
-  OGD_TRY(dimg.alloc((size_t)info.H * info.W));
-  *H = info.H;
-  *W = info.W;
-  return decode_to_device(file, info, dimg.as<uint8_t>(), info.W, as_stream(stream));
+  return parse_and_decode(file, n, 0, 0, 0, nullptr, &dimg, H, W, as_stream(stream));
 }
 
 }  // namespace ogd
@@ -1236,7 +1286,7 @@ int ogd_jpeg_info(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int
 int ogd_jpeg_header(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, int* plausible) {
   OGD_REQUIRE(file && H && W && ncomp && plausible, "null pointer");
   JpegInfo info;
-  OGD_TRY(parse_jpeg(file, n, info, true));
+  OGD_TRY(parse_jpeg(file, n, info, PARSE_HEADERS));
   *H = info.H;
   *W = info.W;
   *ncomp = info.ncomp;
@@ -1247,28 +1297,18 @@ int ogd_jpeg_header(const uint8_t* file, size_t n, int* H, int* W, int* ncomp, i
 
 int ogd_jpeg_decode_gray(const uint8_t* file, size_t n, uint8_t* out, int H, int W, ptrdiff_t stride) {
   OGD_REQUIRE(file && out, "null pointer");
-  JpegInfo info;
-  OGD_TRY(parse_jpeg(file, n, info));
-  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
-  OGD_REQUIRE(H == info.H && W == info.W, "output is %dx%d, the file holds %dx%d", W, H, info.W, info.H);
+  OGD_REQUIRE(H > 0 && W > 0, "output is %dx%d", W, H);
   OGD_REQUIRE(stride >= W, "row stride %td < %d bytes", stride, W);
-  OGD_TRY(ensure_device());
   DevBuf dimg;
-  OGD_TRY(dimg.alloc((size_t)H * W));
-  OGD_TRY(decode_to_device(file, info, dimg.as<uint8_t>(), W, nullptr));
+  OGD_TRY(parse_and_decode(file, n, H, W, W, nullptr, &dimg, nullptr, nullptr, nullptr));
   OGD_HIP(copy_rows(out, (size_t)stride, dimg.p, (size_t)W, (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
   return OGD_OK;
 }
 
 int ogd_jpeg_decode_gray_dev(const uint8_t* file, size_t n, uint8_t* d_out, int H, int W, ptrdiff_t stride, void* stream) {
   OGD_REQUIRE(file && d_out, "null pointer");
-  JpegInfo info;
-  OGD_TRY(parse_jpeg(file, n, info));
-  if (!info.supported) return fail(OGD_ERR_UNSUPPORTED, "JPEG decoder: %s", info.why);
-  OGD_REQUIRE(H == info.H && W == info.W, "output is %dx%d, the file holds %dx%d", W, H, info.W, info.H);
-  OGD_REQUIRE(stride >= W, "row stride %td < %d bytes", stride, W);
-  OGD_TRY(ensure_device());
-  return decode_to_device(file, info, d_out, stride, as_stream(stream));
+  OGD_REQUIRE(H > 0 && W > 0, "output is %dx%d", W, H);
+  return parse_and_decode(file, n, H, W, stride, d_out, nullptr, nullptr, nullptr, as_stream(stream));
 }
 
 }  // extern "C"

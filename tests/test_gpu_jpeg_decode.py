@@ -137,6 +137,30 @@ def test_random_periodic_images(gpu):
 			assert np.array_equal(got, _pil_decode(data)), "case %d: %r %r" % (case, img.shape, params)
 
 
+def test_end_of_scan_taken_on_trust_and_checked_on_the_device(gpu):
+	"""The decode calls take the end of the scan from a trailing EOI marker and let the first device pass find out
+	whether another marker stands inside; then (and for files that do not end in EOI) the host walks the scan as
+	ogd_jpeg_info does.  Same pixels or the same refusal either way."""
+	rng = np.random.default_rng(31)
+	page = synth.text_page(rng, (900, 700))
+	data = ojpeg.save_gray(page)
+	want = _pil_decode(data)
+	assert data[-2:] == b"\xff\xd9"
+	assert np.array_equal(gpu.jpeg_decode_gray(data), want)
+	assert np.array_equal(gpu.jpeg_decode_gray(data + b"\x00\x00\x00"), want)  # bytes behind EOI: the host walks
+	assert np.array_equal(gpu.jpeg_decode_gray(data + b"\xff\xd9"), want)  # a second EOI: the first ends the scan
+	body = bytearray(data)
+	at = len(body) // 2
+	while body[at] == 0xFF or body[at - 1] == 0xFF:
+		at += 1
+	body[at:at] = b"\xff\xd3"  # an RST marker in a file without restart intervals
+	assert gpu.jpeg_info(bytes(body))[3] is False
+	assert gpu.jpeg_decode_gray(bytes(body)) is None
+	body = bytearray(data)
+	body[-3] = 0xFF  # the scan's last byte an 0xFF: FF FF D9 is a fill byte and EOI for libjpeg; refused here
+	assert gpu.jpeg_decode_gray(bytes(body)) is None
+
+
 def test_large_periodic_stream_is_handed_back_in_bounded_time(gpu):
 	"""A 1-pixel checkerboard at quality 100: every block the same ~700 bits, wrong parses are self-consistent and
 	single lanes would walk the whole 5 MB stream (seconds).  The decoder gives up after its time allowance and the
