@@ -307,6 +307,13 @@ int ogd_inflate_zlib(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t cap,
 int ogd_deflate_raw(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out);
 int ogd_deflate_many(const uint8_t* in, const int64_t* offsets, int n, uint8_t* out, int64_t cap,
                      int64_t* out_offsets, uint32_t* crcs);
+/* The reading side (ref: origami/batch/core/io.py:142-144 and origami/core/dewarp.py:537-543 read the archives
+ * through zipfile, one Python-level call per member): member k of an archive held in buf is the raw deflate stream
+ * (methods[k] == 8) or the stored bytes (0) at buf[in_off[k] .. + in_len[k]); it is written to
+ * out[out_off[k] .. out_off[k+1]) — the size the archive's directory states — and checked against crcs[k].
+ * OGD_ERR_INVALID for a corrupt or truncated stream, a wrong size or a wrong CRC-32. */
+int ogd_inflate_many(const uint8_t* buf, int64_t n_buf, const int64_t* in_off, const int64_t* in_len,
+                     const int32_t* methods, int n, uint8_t* out, const int64_t* out_off, const uint32_t* crcs);
 
 /* ---- the march of the node grid on the device -------------------------------------
  * ref: origami/core/dewarp.py:108-140 (Field), :328-339 (GridFactory.grid_shape), :421-439 (grid_h),

@@ -95,6 +95,7 @@ SIGNATURES = {
 	"ogd_inflate_zlib": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
 	"ogd_deflate_raw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
 	"ogd_deflate_many": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+	"ogd_inflate_many": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 	"ogd_wkt_parse": (c_int, [
 		c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
 		POINTER(c_int64)]),
@@ -469,6 +470,7 @@ class DevicePage:
 
 # ---- N3: lattice Delaunay (host) --------------------------------------------------------------------
 
+ERR_INVALID = -1
 ERR_UNSUPPORTED = -5
 ERR_RUNTIME = -6
 
@@ -752,6 +754,28 @@ def deflate_raw(data):
 	n = c_int64(0)
 	check(load().ogd_deflate_raw(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), ctypes.cast(out, c_void_p), cap, ctypes.byref(n)))
 	return out.raw[:n.value]
+
+
+def inflate_many(buf, members):
+	"""The members of a zip archive held in `buf` (bytes), all in one call: members = [(method, crc32, compressed
+	size, size, data offset)] -> list of bytes.  OgdError(ERR_INVALID) for a damaged member."""
+	n = len(members)
+	if n == 0:
+		return []
+	table = np.array(members, dtype=np.int64).reshape(n, 5)
+	methods = np.ascontiguousarray(table[:, 0], dtype=np.int32)
+	crcs = np.ascontiguousarray(table[:, 1], dtype=np.uint32)
+	in_len = np.ascontiguousarray(table[:, 2])
+	in_off = np.ascontiguousarray(table[:, 4])
+	out_off = np.zeros(n + 1, dtype=np.int64)
+	np.cumsum(table[:, 3], out=out_off[1:])
+	out = ctypes.create_string_buffer(max(int(out_off[-1]), 1))
+	check(load().ogd_inflate_many(
+		ctypes.cast(ctypes.c_char_p(buf), c_void_p), len(buf), _ptr(in_off), _ptr(in_len), _ptr(methods), n,
+		ctypes.cast(out, c_void_p), _ptr(out_off), _ptr(crcs)))
+	raw = out.raw
+	bounds = out_off.tolist()
+	return [raw[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
 
 
 def deflate_many(members):

@@ -336,9 +336,14 @@ class Grid:
 	def open(path):
 		"""dewarp.zip: data.npy (float32 node positions) + meta.json {"version", "cell", "shape"}
 		(ref: dewarp.py:537-553, docs/formats.md:272-306)."""
-		with zipfile.ZipFile(path, "r") as zf:
-			meta = json.loads(zf.read("meta.json"))
-			nodes = np.load(io.BytesIO(zf.read("data.npy")), allow_pickle=False)
+		from .batch.core.fastzip import ZipReader
+		if hasattr(path, "read"):
+			members = dict(ZipReader(path).items())
+		else:
+			with open(path, "rb") as f:
+				members = dict(ZipReader(f).items())
+		meta = json.loads(members["meta.json"])
+		nodes = np.load(io.BytesIO(members["data.npy"]), allow_pickle=False)
 		return Grid(nodes.reshape(meta["shape"]), meta["cell"])
 
 	def save(self, path, compression=zipfile.ZIP_DEFLATED):

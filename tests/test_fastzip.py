@@ -1,6 +1,7 @@
 """origami_amd/batch/core/fastzip.py against the zipfile module, in both directions (CPU)."""
 import io
 import zipfile
+import zlib
 
 import pytest
 
@@ -66,6 +67,33 @@ def test_reader_hands_unusual_archives_to_zipfile_and_rejects_damage():
 	damaged[40] ^= 0xFF  # inside the deflate stream
 	with pytest.raises((zipfile.BadZipFile, Exception)):
 		fastzip.ZipReader(bytes(damaged)).read("a.txt")
+
+
+def test_items_inflates_all_members_in_one_call_and_names_damage():
+	"""ZipReader.items() goes through ogd_inflate_many: deflated and stored members, empty ones, archives written by
+	zipfile at several levels (string matches, unlike ZipWriter's literal-only streams); a damaged member raises
+	BadZipFile (or zlib's error from the one-by-one path that names it) and no member of a damaged archive is handed out."""
+	import numpy as np
+	rng = np.random.default_rng(9)
+	members = {"meta.json": b"{}", "empty.bin": b"", "noise.bin": rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+		"text/a.wkt": b"POLYGON ((0 0, 10 0, 10 10, 0 10, 0 0))" * 50, "zeros": bytes(200000)}
+	for level in (0, 1, 6, 9):
+		f = io.BytesIO()
+		with zipfile.ZipFile(f, "w", zipfile.ZIP_DEFLATED if level else zipfile.ZIP_STORED, compresslevel=level or None) as zf:
+			for name, data in members.items():
+				zf.writestr(name, data)
+		assert dict(fastzip.ZipReader(f.getvalue()).items()) == members
+	g = io.BytesIO()
+	with fastzip.ZipWriter(g) as zf:
+		for name, data in members.items():
+			zf.writestr(name, data)
+	assert dict(fastzip.ZipReader(g.getvalue()).items()) == members
+	whole = g.getvalue()
+	at = whole.index(b"noise.bin") + len(b"noise.bin") + 1000  # inside the member's data
+	for damaged in (whole[:at] + bytes([whole[at] ^ 0x55]) + whole[at + 1:],):
+		with pytest.raises(Exception) as info:
+			dict(fastzip.ZipReader(damaged).items())
+		assert isinstance(info.value, (zipfile.BadZipFile, zlib.error)), info.value
 
 
 def test_writer_leaves_nothing_behind_when_the_block_raises():

@@ -95,6 +95,12 @@ def main():
 		t_dec = time.perf_counter() - t
 		print("utils.dewarp stage (page JPG -> annotation.dewarped.jpg): %.3f s = %.1f ms/page (PIL would decode such a page in %.1f ms)" % (
 			dt, 1e3 * dt / n_pages, 1e3 * t_dec))
+		if not workers and os.environ.get("STAGE_PROFILE_JPG"):
+			pr = cProfile.Profile()
+			pr.enable()
+			run_image_stage()
+			pr.disable()
+			pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 		for k in range(n_pages):  # back to PNG pages for the profile below
 			jpg = root / ("page%04d.jpg" % k)
 			im.save(jpg.with_suffix(".png"), compress_level=1)
