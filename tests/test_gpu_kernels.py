@@ -189,6 +189,48 @@ def test_fused_dewarp_equals_fill_then_remap(gpu, C):
 	assert (got > 0).mean() > 0.5
 
 
+def test_remap_and_fused_dewarp_random_cases(gpu):
+	"""Thirty-six seeded random cases through K2 and the fused kernel against the oracle, bit for bit: source and
+	output sizes that are no multiples of any tile, 1 / 3 / 4 channels, both interpolations, maps that are smooth,
+	strongly sheared (windows beyond the LDS budget: the global-gather path), folded over themselves or leave the
+	image; node grids of random cell size with warps of up to a cell, scaled for the label-map case."""
+	rng = np.random.default_rng(4242)
+	for case in range(36):
+		C = int(rng.choice([1, 1, 3, 4]))
+		interp = int(rng.choice([ocv.INTER_LINEAR, ocv.INTER_LINEAR, ocv.INTER_NEAREST]))
+		H, W = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+		src = rng.integers(0, 256, size=(H, W, C), dtype=np.uint8)
+		if C == 1:
+			src = src[:, :, 0]
+		msg = "case %d: C=%d interp=%d src %dx%d" % (case, C, interp, W, H)
+		if case % 2 == 0:  # K2 through a dense map
+			Hd, Wd = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+			yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+			kind = case % 8
+			if kind == 0:
+				m = np.stack([xx * (W / Wd), yy * (H / Hd)], -1) + rng.normal(0, 0.4, (Hd, Wd, 2))
+			elif kind == 2:
+				m = np.stack([xx * 3.7 - yy * 2.9, yy * 4.1 + xx * 1.3], -1)  # sheared: wide windows
+			elif kind == 4:
+				m = np.stack([np.abs(W / 2 - xx * 1.5), np.abs(H / 2 - yy * 1.5)], -1)  # folded
+			else:
+				m = rng.uniform([-W, -H], [2 * W, 2 * H], (Hd, Wd, 2))  # mostly outside, incoherent
+			m = m.astype(np.float32)
+			np.testing.assert_array_equal(gpu.remap_u8(src, m, interp), ocv.remap_u8(src, m, interp), err_msg=msg)
+		else:  # the fused kernel through a node grid
+			s = int(rng.integers(1, 40))
+			h, w = int(rng.integers(1, 16)), int(rng.integers(1, 16))
+			gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+			nodes = np.stack([(gx - 1) * s * W / max(1, (w - 2) * s), (gy - 1) * s * H / max(1, (h - 2) * s)], -1)
+			nodes = (nodes + rng.normal(0, 0.5 * s, nodes.shape)).astype(np.float32)
+			sx, sy = (1.0, 1.0) if rng.random() < 0.6 else (float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2)))
+			want_map = ocv.dense_grid(nodes, s)
+			want_map[:, :, 0] *= np.float32(sx)
+			want_map[:, :, 1] *= np.float32(sy)
+			want = ocv.remap_u8(src, want_map, interp)
+			np.testing.assert_array_equal(gpu.dewarp_u8(src, nodes, s, sx, sy, interp), want, err_msg=msg + " cell %d nodes %dx%d" % (s, w, h))
+
+
 def test_remap_rejects_bad_arguments(gpu):
 	src = np.zeros((4, 4, 2), dtype=np.uint8)
 	m = np.zeros((4, 4, 2), dtype=np.float32)
