@@ -42,6 +42,10 @@ int ensure_device();
 // ogd_trim() gives the calling thread's idle blocks back.
 void* pool_take(size_t bytes);  // nullptr on failure (error already set)
 void pool_give(void* p);
+// A pinned host buffer of the calling thread for packing several small uploads into one asynchronous copy (a
+// synchronous copy from pageable memory costs ~60 us whatever its size).  Valid until the thread's next call; the
+// caller synchronises before it returns.  nullptr if pinned memory cannot be had: copy from where the data lies.
+void* staging_host(size_t bytes);
 
 // A device buffer held for the duration of one host-buffer entry point.
 struct DevBuf {

@@ -127,6 +127,31 @@ void pool_give(void* p) {
   (void)hipFree(p);  // not ours (cannot happen through DevBuf)
 }
 
+struct Staging {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~Staging() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+static thread_local Staging g_staging;
+
+void* staging_host(size_t bytes) {
+  if (bytes <= g_staging.bytes) return g_staging.p;
+  if (g_staging.p) (void)hipHostFree(g_staging.p);
+  g_staging.p = nullptr;
+  g_staging.bytes = 0;
+  const size_t rounded = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  void* p = nullptr;
+  if (hipHostMalloc(&p, rounded, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  g_staging.p = p;
+  g_staging.bytes = rounded;
+  return p;
+}
+
 static size_t pool_trim() {
   size_t freed = 0;
   for (auto& b : g_pool.blocks)

@@ -565,13 +565,46 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
   h->inv_cw = 1.0 / cw; h->inv_ch = 1.0 / ch;
   auto build = [&]() -> int {
     DevBuf dpts, dsimp, dcursor, dscalars, dbig, dtransform, dvals;
-    OGD_TRY(dpts.alloc((size_t)n * 2 * sizeof(double)));
-    OGD_TRY(dsimp.alloc((size_t)nt * 3 * sizeof(int32_t)));
-    OGD_TRY(dvals.alloc((size_t)n * nv * sizeof(double)));
-    OGD_HIP(hipMemcpy(dvals.p, vals, (size_t)n * nv * sizeof(double), hipMemcpyHostToDevice));
-    if (transform) {
-      OGD_TRY(dtransform.alloc((size_t)nt * 6 * sizeof(double)));
-      OGD_HIP(hipMemcpy(dtransform.p, transform, (size_t)nt * 6 * sizeof(double), hipMemcpyHostToDevice));
+    // The four inputs: a triangulation of a few thousand triangles (the angle fields, the extrapolation sets: five of
+    // a page's six) packs them into the thread's pinned staging buffer and uploads them with ONE asynchronous copy —
+    // four synchronous copies from pageable memory are 250 us of such a handle's 450; a broadsheet lattice (15 MB) goes
+    // up from where it lies.
+    const size_t b_pts = (size_t)n * 2 * sizeof(double), b_simp = (size_t)nt * 3 * sizeof(int32_t);
+    const size_t b_vals = (size_t)n * nv * sizeof(double), b_tr = transform ? (size_t)nt * 6 * sizeof(double) : 0;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_simp = pad(b_pts), o_vals = o_simp + pad(b_simp), o_tr = o_vals + pad(b_vals), b_all = o_tr + pad(b_tr);
+    char* stage = b_all <= ((size_t)1 << 20) ? static_cast<char*>(staging_host(b_all)) : nullptr;
+    const double2* p_pts;
+    const int32_t* p_simp;
+    const double* p_vals;
+    const double* p_tr = nullptr;
+    if (stage) {
+      OGD_TRY(dpts.alloc(b_all));
+      std::memcpy(stage, pts, b_pts);
+      std::memcpy(stage + o_simp, simplices, b_simp);
+      std::memcpy(stage + o_vals, vals, b_vals);
+      if (transform) std::memcpy(stage + o_tr, transform, b_tr);
+      OGD_HIP(hipMemcpyAsync(dpts.p, stage, b_all, hipMemcpyHostToDevice, nullptr));
+      char* base = dpts.as<char>();
+      p_pts = reinterpret_cast<const double2*>(base);
+      p_simp = reinterpret_cast<const int32_t*>(base + o_simp);
+      p_vals = reinterpret_cast<const double*>(base + o_vals);
+      if (transform) p_tr = reinterpret_cast<const double*>(base + o_tr);
+    } else {
+      OGD_TRY(dpts.alloc(b_pts));
+      OGD_TRY(dsimp.alloc(b_simp));
+      OGD_TRY(dvals.alloc(b_vals));
+      OGD_HIP(hipMemcpy(dvals.p, vals, b_vals, hipMemcpyHostToDevice));
+      if (transform) {
+        OGD_TRY(dtransform.alloc(b_tr));
+        OGD_HIP(hipMemcpy(dtransform.p, transform, b_tr, hipMemcpyHostToDevice));
+        p_tr = dtransform.as<double>();
+      }
+      OGD_HIP(hipMemcpy(dpts.p, pts, b_pts, hipMemcpyHostToDevice));
+      OGD_HIP(hipMemcpy(dsimp.p, simplices, b_simp, hipMemcpyHostToDevice));
+      p_pts = dpts.as<double2>();
+      p_simp = dsimp.as<int32_t>();
+      p_vals = dvals.as<double>();
     }
     {
       const size_t bytes = (size_t)nt * rec * sizeof(double);
@@ -581,8 +614,6 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     OGD_TRY(dcursor.alloc((size_t)ncell * sizeof(int)));
     OGD_TRY(dscalars.alloc(32));  // long long total | int max_cell | int nbig | int nlong
     OGD_TRY(dbig.alloc((size_t)nt * sizeof(int)));
-    OGD_HIP(hipMemcpy(dpts.p, pts, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
-    OGD_HIP(hipMemcpy(dsimp.p, simplices, (size_t)nt * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
     OGD_HIP(hipMalloc((void**)&h->d_cell_start, (size_t)(ncell + 1) * sizeof(int)));
     OGD_HIP(hipMemsetAsync(h->d_cell_start, 0, (size_t)(ncell + 1) * sizeof(int), nullptr));
     OGD_HIP(hipMemsetAsync(dscalars.p, 0, 32, nullptr));
@@ -590,12 +621,12 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     int* d_nbig = reinterpret_cast<int*>(dscalars.as<char>() + 12);
     const dim3 tgrid((unsigned)((nt + 255) / 256)), tblock(256);
     // the triangle records are assembled on the device (a broadsheet Transformer has 157 k of them, 15 MB)
-    hipLaunchKernelGGL(tri_records_kernel, tgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
-                       transform ? dtransform.as<double>() : (const double*)nullptr, dvals.as<double>(), nv, nt,
+    hipLaunchKernelGGL(tri_records_kernel, tgrid, tblock, 0, nullptr, p_pts, p_simp,
+                       p_tr, p_vals, nv, nt,
                        h->d_rec, rec);
     OGD_TRY(check_launch("tri_records_kernel"));
-    hipLaunchKernelGGL(bucket_scatter_kernel<false>, tgrid, tblock, 0, nullptr, dpts.as<double2>(),
-                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, d_total,
+    hipLaunchKernelGGL(bucket_scatter_kernel<false>, tgrid, tblock, 0, nullptr, p_pts,
+                       p_simp, h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, d_total,
                        dbig.as<int>(), d_nbig);
     OGD_TRY(check_launch("bucket_scatter_kernel<count>"));
     int nbig = 0;
@@ -603,7 +634,7 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     OGD_REQUIRE(nbig >= 0 && nbig <= nt, "bucket grid: %d large triangles of %d", nbig, nt);
     const dim3 bgrid((unsigned)((nbig + 3) / 4));
     if (nbig > 0) {
-      hipLaunchKernelGGL(bucket_big_kernel<false>, bgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
+      hipLaunchKernelGGL(bucket_big_kernel<false>, bgrid, tblock, 0, nullptr, p_pts, p_simp,
                          h->d_rec, rec, geom, h->d_cell_start, (int*)nullptr, d_total, dbig.as<int>(), nbig);
       OGD_TRY(check_launch("bucket_big_kernel<count>"));
     }
@@ -621,12 +652,12 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
 
     OGD_HIP(hipMalloc((void**)&h->d_cell_tris, (size_t)std::max(total, 1) * sizeof(int)));
     OGD_HIP(hipMemcpyAsync(dcursor.p, h->d_cell_start, (size_t)ncell * sizeof(int), hipMemcpyDeviceToDevice, nullptr));
-    hipLaunchKernelGGL(bucket_scatter_kernel<true>, tgrid, tblock, 0, nullptr, dpts.as<double2>(),
-                       dsimp.as<int32_t>(), h->d_rec, rec, nt, geom, dcursor.as<int>(), h->d_cell_tris,
+    hipLaunchKernelGGL(bucket_scatter_kernel<true>, tgrid, tblock, 0, nullptr, p_pts,
+                       p_simp, h->d_rec, rec, nt, geom, dcursor.as<int>(), h->d_cell_tris,
                        (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr);
     OGD_TRY(check_launch("bucket_scatter_kernel<fill>"));
     if (nbig > 0) {
-      hipLaunchKernelGGL(bucket_big_kernel<true>, bgrid, tblock, 0, nullptr, dpts.as<double2>(), dsimp.as<int32_t>(),
+      hipLaunchKernelGGL(bucket_big_kernel<true>, bgrid, tblock, 0, nullptr, p_pts, p_simp,
                          h->d_rec, rec, geom, dcursor.as<int>(), h->d_cell_tris, (unsigned long long*)nullptr,
                          dbig.as<int>(), nbig);
       OGD_TRY(check_launch("bucket_big_kernel<fill>"));
