@@ -150,6 +150,12 @@ int ogd_jpeg_decode_gray_dev(const uint8_t* file, size_t n, uint8_t* d_out, int 
 typedef struct ogd_tri ogd_tri;
 int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt,
                    const double* transform, const double* vals, int nv, ogd_tri** out);
+/* The same with scipy Delaunay.transform itself computed on the device (the LAPACK-style LU inverse with its
+ * condition check, NaN rows for degenerate simplices: bit for bit what ogd_lattice_delaunay / ogd_delaunay_points
+ * write with a non-NULL `transform`), for callers that got their simplices from those two with transform = NULL:
+ * neither the host loop nor the 48 bytes per simplex of upload.  ref: lingrid.py:286-290. */
+int ogd_tri_create_scipy(const double* pts, int n, const int32_t* simplices, int nt,
+                         const double* vals, int nv, ogd_tri** out);
 int ogd_tri_destroy(ogd_tri* t);
 /* q: [nq][2] float64 -> out: [nq][nv] float64.  Points are clipped to bounds = {minx,miny,maxx,maxy}
  * (NULL = no clip), looked up in `inner` (may be NULL) and, where that yields NaN, in `extra`. */

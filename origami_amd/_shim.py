@@ -61,6 +61,8 @@ SIGNATURES = {
 		c_void_p, c_ssize_t, c_int, c_void_p]),
 	"ogd_tri_create": (c_int, [
 		c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]),
+	"ogd_tri_create_scipy": (c_int, [
+		c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, POINTER(c_void_p)]),
 	"ogd_tri_destroy": (c_int, [c_void_p]),
 	"ogd_tri_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 	"ogd_tri_eval_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -475,49 +477,53 @@ ERR_UNSUPPORTED = -5
 ERR_RUNTIME = -6
 
 
-def lattice_delaunay(points_hw2):
+def lattice_delaunay(points_hw2, transform=True):
 	"""(h, w, 2) lattice positions -> (simplices (nt, 3) int32, hull vertex indices, transform (nt, 3, 2)),
-	as scipy.spatial.Delaunay / ConvexHull give them; raises OgdError(ERR_UNSUPPORTED) outside its domain."""
+	as scipy.spatial.Delaunay / ConvexHull give them; raises OgdError(ERR_UNSUPPORTED) outside its domain.
+	transform=False: None in its place (Triangulation(..., scipy_transform=True) computes it on the device)."""
 	pts = _c(points_hw2, np.float64)
 	if pts.ndim != 3 or pts.shape[2] != 2:
 		raise ValueError("lattice must have shape (h, w, 2)")
 	h, w = pts.shape[:2]
 	cap = 2 * h * w
 	simplices = np.empty((cap, 3), dtype=np.int32)
-	transform = np.empty((cap, 3, 2), dtype=np.float64)
+	transform = np.empty((cap, 3, 2), dtype=np.float64) if transform else None
 	hull = np.empty(2 * (h + w), dtype=np.int32)
 	nt, nh = c_int64(0), c_int(0)
 	check(load().ogd_lattice_delaunay(
-		_ptr(pts), h, w, _ptr(simplices), cap, ctypes.byref(nt), _ptr(hull), ctypes.byref(nh), _ptr(transform)))
-	return simplices[:nt.value], hull[:nh.value], transform[:nt.value]
+		_ptr(pts), h, w, _ptr(simplices), cap, ctypes.byref(nt), _ptr(hull), ctypes.byref(nh),
+		_ptr(transform) if transform is not None else None))
+	return simplices[:nt.value], hull[:nh.value], transform[:nt.value] if transform is not None else None
 
 
-def delaunay_points(points, twins=False):
+def delaunay_points(points, twins=False, transform=True):
 	"""(n, 2) scattered points -> (simplices (nt, 3) int32, transform (nt, 3, 2), n_ties) as scipy.spatial.Delaunay
 	gives them when n_ties == 0; raises OgdError(ERR_UNSUPPORTED) for collinear / too few points and, unless
 	twins=True, for coincident points.  twins=True appends a fourth result: twin (n,) int32, -1 for triangulated
-	points, else the index of the coincident point that stands for this one."""
+	points, else the index of the coincident point that stands for this one.  transform=False: None in its place."""
 	pts = _c(points, np.float64)
 	if pts.ndim != 2 or pts.shape[1] != 2:
 		raise ValueError("points must have shape (n, 2)")
 	cap = 2 * len(pts) + 4
 	simplices = np.empty((cap, 3), dtype=np.int32)
-	transform = np.empty((cap, 3, 2), dtype=np.float64)
+	transform = np.empty((cap, 3, 2), dtype=np.float64) if transform else None
 	twin = np.empty(len(pts), dtype=np.int32) if twins else None
 	nt, ties = c_int64(0), c_int64(0)
 	check(load().ogd_delaunay_points(
-		_ptr(pts), len(pts), _ptr(simplices), cap, ctypes.byref(nt), _ptr(transform), ctypes.byref(ties),
-		_ptr(twin) if twins else None))
-	out = (simplices[:nt.value], transform[:nt.value], ties.value)
+		_ptr(pts), len(pts), _ptr(simplices), cap, ctypes.byref(nt),
+		_ptr(transform) if transform is not None else None, ctypes.byref(ties), _ptr(twin) if twins else None))
+	out = (simplices[:nt.value], transform[:nt.value] if transform is not None else None, ties.value)
 	return out + (twin,) if twins else out
 
 
 # ---- K3 / K1b -------------------------------------------------------------------------------------
 
 class Triangulation:
-	"""Device-resident piecewise-linear interpolant over a host (Qhull) triangulation."""
+	"""Device-resident piecewise-linear interpolant over a host (Qhull) triangulation.  Without `transform`:
+	scipy_transform=True computes scipy.spatial.Delaunay's transform on the device (bit for bit the one
+	lattice_delaunay / delaunay_points return), False the plain fp64 inverse of the edge matrix."""
 
-	def __init__(self, points, simplices, values, transform=None):
+	def __init__(self, points, simplices, values, transform=None, scipy_transform=False):
 		points = _c(points, np.float64)
 		simplices = _c(simplices, np.int32)
 		values = _c(values, np.float64)
@@ -531,10 +537,15 @@ class Triangulation:
 			raise ValueError("one value row per point expected")
 		self.nv = values.shape[1]
 		self._h = c_void_p()
-		check(load().ogd_tri_create(
-			_ptr(points), len(points), _ptr(simplices), len(simplices),
-			_ptr(transform) if transform is not None else None, _ptr(values), self.nv,
-			ctypes.byref(self._h)))
+		if transform is None and scipy_transform:
+			check(load().ogd_tri_create_scipy(
+				_ptr(points), len(points), _ptr(simplices), len(simplices), _ptr(values), self.nv,
+				ctypes.byref(self._h)))
+		else:
+			check(load().ogd_tri_create(
+				_ptr(points), len(points), _ptr(simplices), len(simplices),
+				_ptr(transform) if transform is not None else None, _ptr(values), self.nv,
+				ctypes.byref(self._h)))
 
 	@property
 	def handle(self):

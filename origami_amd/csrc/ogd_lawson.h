@@ -93,45 +93,51 @@ int lawson_flips(const P& L, std::vector<int32_t>& T, std::vector<int32_t>& N, s
   return OGD_OK;
 }
 
-// scipy.spatial.Delaunay.transform for nt triangles: rows 0-1 = inverse of [[x0 - x2, x1 - x2], [y0 - y2, y1 - y2]],
-// row 2 = vertex 2; LU with partial pivoting as LAPACK's dgetrf / dgetrs order the operations; NaN where the
-// reciprocal condition number (1-norm) is below 1000 eps (scipy's rcond_limit).  transform: [nt][3][2].
-inline void simplex_transforms(const double* pts, const int32_t* T, int64_t nt, double* transform) {
+// scipy.spatial.Delaunay.transform of ONE triangle: o[0..3] = inverse of [[x0 - x2, x1 - x2], [y0 - y2, y1 - y2]],
+// o[4..5] = vertex 2; LU with partial pivoting as LAPACK's dgetrf / dgetrs order the operations; NaN where the
+// reciprocal condition number (1-norm) is below 1000 eps (scipy's rcond_limit).  Host and device run this very
+// source (no contraction on either side, IEEE division on both): ogd_tri_create_scipy computes on the GPU what
+// simplex_transforms computes here, bit for bit.
+__host__ __device__ inline void simplex_transform_one(const double* p0, const double* p1, const double* p2, double* o) {
   const double rcond_limit = 1000.0 * 2.220446049250313e-16;
-  const double nan = std::nan("");
-  parallel_ranges(nt, 16384, [=](int64_t t_begin, int64_t t_end) {
-  for (int64_t t = t_begin; t < t_end; ++t) {
-    const double* p0 = pts + 2 * (size_t)T[3 * t], *p1 = pts + 2 * (size_t)T[3 * t + 1], *p2 = pts + 2 * (size_t)T[3 * t + 2];
-    const double a00 = p0[0] - p2[0], a01 = p1[0] - p2[0], a10 = p0[1] - p2[1], a11 = p1[1] - p2[1];
-    double* o = transform + 6 * t;
-    o[4] = p2[0];
-    o[5] = p2[1];
-    // scipy passes its row-major T to column-major LAPACK: the factored matrix is M = T^T and the solution
-    // of M X = I, read back row-major, is X^T = T^-1
-    const double m00 = a00, m01 = a10, m10 = a01, m11 = a11;
-    const bool swap = std::fabs(m10) > std::fabs(m00);
-    const double u00 = swap ? m10 : m00, u01 = swap ? m11 : m01, l10n = swap ? m00 : m10, r1 = swap ? m01 : m11;
-    bool ok = u00 != 0.0;
-    double i00 = nan, i01 = nan, i10 = nan, i11 = nan;
+  const double nan = __builtin_nan("");
+  const double a00 = p0[0] - p2[0], a01 = p1[0] - p2[0], a10 = p0[1] - p2[1], a11 = p1[1] - p2[1];
+  o[4] = p2[0];
+  o[5] = p2[1];
+  // scipy passes its row-major T to column-major LAPACK: the factored matrix is M = T^T and the solution
+  // of M X = I, read back row-major, is X^T = T^-1
+  const double m00 = a00, m01 = a10, m10 = a01, m11 = a11;
+  const bool swap = fabs(m10) > fabs(m00);
+  const double u00 = swap ? m10 : m00, u01 = swap ? m11 : m01, l10n = swap ? m00 : m10, r1 = swap ? m01 : m11;
+  bool ok = u00 != 0.0;
+  double i00 = nan, i01 = nan, i10 = nan, i11 = nan;
+  if (ok) {
+    const double l10 = l10n * (1.0 / u00);
+    const double u11 = r1 - l10 * u01;
+    ok = u11 != 0.0;
     if (ok) {
-      const double l10 = l10n * (1.0 / u00);
-      const double u11 = r1 - l10 * u01;
-      ok = u11 != 0.0;
-      if (ok) {
-        const double b00 = swap ? 0.0 : 1.0, b10 = swap ? 1.0 : 0.0;  // column 0 of P I (P: the row swap)
-        const double b01 = swap ? 1.0 : 0.0, b11 = swap ? 0.0 : 1.0;  // column 1
-        const double y10 = b10 - l10 * b00, y11 = b11 - l10 * b01;
-        const double x10 = y10 / u11, x11 = y11 / u11;
-        const double x00 = (b00 - u01 * x10) / u00, x01 = (b01 - u01 * x11) / u00;
-        i00 = x00; i01 = x10; i10 = x01; i11 = x11;
-        const double anorm = std::max(std::fabs(m00) + std::fabs(m10), std::fabs(m01) + std::fabs(m11));
-        const double inorm = std::max(std::fabs(x00) + std::fabs(x10), std::fabs(x01) + std::fabs(x11));
-        const double rcond = 1.0 / (anorm * inorm);
-        if (!(rcond >= rcond_limit)) ok = false;
-      }
+      const double b00 = swap ? 0.0 : 1.0, b10 = swap ? 1.0 : 0.0;  // column 0 of P I (P: the row swap)
+      const double b01 = swap ? 1.0 : 0.0, b11 = swap ? 0.0 : 1.0;  // column 1
+      const double y10 = b10 - l10 * b00, y11 = b11 - l10 * b01;
+      const double x10 = y10 / u11, x11 = y11 / u11;
+      const double x00 = (b00 - u01 * x10) / u00, x01 = (b01 - u01 * x11) / u00;
+      i00 = x00; i01 = x10; i10 = x01; i11 = x11;
+      const double an0 = fabs(m00) + fabs(m10), an1 = fabs(m01) + fabs(m11);
+      const double in0 = fabs(x00) + fabs(x10), in1 = fabs(x01) + fabs(x11);
+      const double anorm = an0 > an1 ? an0 : an1, inorm = in0 > in1 ? in0 : in1;
+      const double rcond = 1.0 / (anorm * inorm);
+      if (!(rcond >= rcond_limit)) ok = false;
     }
-    o[0] = ok ? i00 : nan; o[1] = ok ? i01 : nan; o[2] = ok ? i10 : nan; o[3] = ok ? i11 : nan;
   }
+  o[0] = ok ? i00 : nan; o[1] = ok ? i01 : nan; o[2] = ok ? i10 : nan; o[3] = ok ? i11 : nan;
+}
+
+// scipy.spatial.Delaunay.transform for nt triangles; transform: [nt][3][2].
+inline void simplex_transforms(const double* pts, const int32_t* T, int64_t nt, double* transform) {
+  parallel_ranges(nt, 16384, [=](int64_t t_begin, int64_t t_end) {
+    for (int64_t t = t_begin; t < t_end; ++t)
+      simplex_transform_one(pts + 2 * (size_t)T[3 * t], pts + 2 * (size_t)T[3 * t + 1], pts + 2 * (size_t)T[3 * t + 2],
+                            transform + 6 * t);
   });
 }
 

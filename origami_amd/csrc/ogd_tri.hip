@@ -17,6 +17,7 @@
 // Triangle record (fp64): {T00, T01, T10, T11, r0, r1, v0[nv], v1[nv], v2[nv]} = 72 B (nv=1), 96 B (nv=2).
 #include "ogd_common.h"
 #include "ogd_tri_dev.h"
+#include "ogd_lawson.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
@@ -487,9 +488,11 @@ struct BindDevice {
 
 // Triangle record t = {T00, T01, T10, T11, r0, r1, v0[nv], v1[nv], v2[nv]}: the barycentric transform as given
 // (scipy's Delaunay.transform layout) or, without one, the plain inverse of the edge matrix (columns v0 - v2, v1 - v2).
+// scipy_lu (with transform == NULL): the transform scipy.spatial.Delaunay would hand out, computed here
+// (simplex_transform_one, the source the host runs for ogd_lattice_delaunay / ogd_delaunay_points).
 __global__ __launch_bounds__(256) void tri_records_kernel(const double2* __restrict__ pts, const int32_t* __restrict__ simplices,
                                                           const double* __restrict__ transform, const double* __restrict__ vals,
-                                                          int nv, int nt, double* __restrict__ recs, int rec) {
+                                                          int nv, int nt, double* __restrict__ recs, int rec, bool scipy_lu) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
   const int32_t s0 = simplices[3 * (size_t)t], s1 = simplices[3 * (size_t)t + 1], s2 = simplices[3 * (size_t)t + 2];
@@ -497,6 +500,12 @@ __global__ __launch_bounds__(256) void tri_records_kernel(const double2* __restr
   if (transform) {
     const double* T = transform + 6 * (size_t)t;
     for (int k = 0; k < 6; ++k) r[k] = T[k];
+  } else if (scipy_lu) {
+    const double2 p0 = pts[s0], p1 = pts[s1], p2 = pts[s2];
+    const double a[2] = {p0.x, p0.y}, b[2] = {p1.x, p1.y}, c[2] = {p2.x, p2.y};
+    double o[6];
+    simplex_transform_one(a, b, c, o);
+    for (int k = 0; k < 6; ++k) r[k] = o[k];
   } else {
     const double2 p0 = pts[s0], p1 = pts[s1], p2 = pts[s2];
     const double ax = __dsub_rn(p0.x, p2.x), bx = __dsub_rn(p1.x, p2.x);
@@ -524,8 +533,8 @@ using namespace ogd;
 
 extern "C" {
 
-int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, const double* transform,
-                   const double* vals, int nv, ogd_tri** out) {
+static int tri_create(const double* pts, int n, const int32_t* simplices, int nt, const double* transform,
+                      bool scipy_lu, const double* vals, int nv, ogd_tri** out) {
   OGD_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   OGD_REQUIRE(pts && simplices && vals, "null pointer");
@@ -623,7 +632,7 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
     // the triangle records are assembled on the device (a broadsheet Transformer has 157 k of them, 15 MB)
     hipLaunchKernelGGL(tri_records_kernel, tgrid, tblock, 0, nullptr, p_pts, p_simp,
                        p_tr, p_vals, nv, nt,
-                       h->d_rec, rec);
+                       h->d_rec, rec, scipy_lu);
     OGD_TRY(check_launch("tri_records_kernel"));
     hipLaunchKernelGGL(bucket_scatter_kernel<false>, tgrid, tblock, 0, nullptr, p_pts,
                        p_simp, h->d_rec, rec, nt, geom, h->d_cell_start, (int*)nullptr, d_total,
@@ -683,6 +692,16 @@ int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, c
   }
   *out = h;
   return OGD_OK;
+}
+
+int ogd_tri_create(const double* pts, int n, const int32_t* simplices, int nt, const double* transform,
+                   const double* vals, int nv, ogd_tri** out) {
+  return tri_create(pts, n, simplices, nt, transform, false, vals, nv, out);
+}
+
+int ogd_tri_create_scipy(const double* pts, int n, const int32_t* simplices, int nt, const double* vals, int nv,
+                         ogd_tri** out) {
+  return tri_create(pts, n, simplices, nt, nullptr, true, vals, nv, out);
 }
 
 int ogd_tri_destroy(ogd_tri* t) {

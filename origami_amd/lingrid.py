@@ -210,7 +210,7 @@ class InterpolatorFactory:
 		if lattice_shape is not None and tuple(lattice_shape) >= (2, 2):
 			h, w = lattice_shape
 			try:
-				self._lattice = _shim.lattice_delaunay(pts.reshape(h, w, 2))
+				self._lattice = _shim.lattice_delaunay(pts.reshape(h, w, 2), transform=False)
 			except _shim.OgdError as e:
 				if e.status != _shim.ERR_UNSUPPORTED:
 					raise
@@ -269,7 +269,8 @@ class InterpolatorFactory:
 		# flips, host) returns Qhull's simplices at a fraction of the time; with cocircular ties, coincident points
 		# of different values or collinear points it is Qhull itself, scipy's Delaunay defaults ("Qbb Qc Qz Q12" + "Qt"), that decides.
 		try:
-			simplices, transform, ties, twin = _shim.delaunay_points(points, twins=True)
+			simplices, _, ties, twin = _shim.delaunay_points(points, twins=True, transform=False)
+			transform = None  # computed on the device, as scipy computes it (ogd_tri_create_scipy)
 			dropped = np.flatnonzero(twin >= 0)
 			if len(dropped) and not np.array_equal(np.asarray(values)[dropped], np.asarray(values)[twin[dropped]]):
 				ties = -1  # coincident points with different values: the answer depends on which one Qhull keeps
@@ -280,7 +281,7 @@ class InterpolatorFactory:
 		if ties != 0:
 			tri = scipy.spatial.Delaunay(points)
 			simplices, transform = tri.simplices, tri.transform
-		return _shim.Triangulation(points, simplices, values, transform)
+		return _shim.Triangulation(points, simplices, values, transform, scipy_transform=True)
 
 	@property
 	def interpolator(self):
@@ -288,8 +289,8 @@ class InterpolatorFactory:
 			extra = self._triangulate(self._extra_pts, self._extra_val)
 			inter = None
 			if self._lattice is not None:
-				simplices, _, transform = self._lattice
-				inter = _shim.Triangulation(self._points, simplices, self._values, transform)
+				simplices, _, _ = self._lattice
+				inter = _shim.Triangulation(self._points, simplices, self._values, scipy_transform=True)
 				self._lattice = None
 			elif not self._is_collinear:
 				inter = self._triangulate(self._points, self._values)

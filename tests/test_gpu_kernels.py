@@ -271,7 +271,7 @@ def triangulator(request, monkeypatch):
 	if request.param == "qhull":
 		from origami_amd import _shim
 
-		def refuse(points, twins=False):
+		def refuse(points, twins=False, transform=True):
 			raise _shim.OgdError(_shim.ERR_UNSUPPORTED, "forced by the test")
 		monkeypatch.setattr(_shim, "delaunay_points", refuse)
 	return request.param
@@ -311,6 +311,49 @@ def test_tri_eval_collinear_and_errors(gpu, triangulator):
 	_close(got_fac.interpolator(q), want_f(q), same_bits=triangulator == "qhull")
 	with pytest.raises(ValueError, match="not enough values"):
 		lininterp(pts[:1], vals[:1], bounds)
+
+
+def test_transform_computed_on_the_device_is_the_hosts(gpu):
+	"""ogd_tri_create_scipy against ogd_tri_create fed the transform ogd_lattice_delaunay / ogd_delaunay_points
+	write (scipy's, tests/test_host.py): one source for both, so every interpolated value has the same bits;
+	slivers and flat simplices (scipy's NaN rows) included."""
+	from origami_amd import _shim
+	rng = np.random.default_rng(11)
+	# a sheared lattice with a few collinear border triples, and scattered points with near-degenerate slivers
+	h, w = 23, 31
+	yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+	nodes = np.stack([xx * 40 + yy * 3 + rng.uniform(-6, 6, (h, w)), yy * 40 + rng.uniform(-6, 6, (h, w))], axis=-1)
+	nodes = np.round(nodes * 1024) / 1024  # the lattice route wants coordinates it can do exact arithmetic on
+	simplices, _, transform = _shim.lattice_delaunay(nodes)
+	cases = [(nodes.reshape(-1, 2), simplices, transform)]
+	pts = rng.uniform(0, 1000, (3000, 2))
+	pts[:200, 1] = pts[:200, 0] * 0.5 + rng.uniform(-1e-9, 1e-9, 200)  # nearly collinear run
+	simplices, transform, _ = _shim.delaunay_points(pts)
+	cases.append((pts, simplices, transform))
+	# flat simplices given by hand: the transform has NaN rows, the interpolant skips them
+	flat_pts = np.array([[0, 0], [1, 1], [2, 2], [0, 2], [3, 3]], dtype=np.float64)
+	flat_simp = np.array([[0, 1, 2], [0, 2, 3], [0, 1, 4]], dtype=np.int32)
+	cases.append((flat_pts, flat_simp, None))
+	for points, simp, tr in cases:
+		vals = rng.normal(size=(len(points), 2))
+		lo, hi = points.min(axis=0), points.max(axis=0)
+		q = np.concatenate([rng.uniform(lo - 5, hi + 5, size=(20000, 2)), points[:50]])
+		device = _shim.Triangulation(points, simp, vals, scipy_transform=True)
+		if tr is None:
+			a, b, c = (points[simp[:, k]] for k in range(3))
+			assert np.any(np.cross(a - c, b - c) == 0)
+			tr = np.empty((len(simp), 3, 2))
+			for t in range(len(simp)):
+				T = np.array([a[t] - c[t], b[t] - c[t]]).T
+				tr[t, :2] = np.linalg.inv(T) if np.linalg.matrix_rank(T) == 2 else np.nan
+				tr[t, 2] = c[t]
+			got = _shim.tri_eval(None, device, None, q)
+			want = _shim.tri_eval(None, _shim.Triangulation(points, simp, vals, tr), None, q)
+			assert np.array_equal(np.isnan(got), np.isnan(want))
+			np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+			continue
+		host = _shim.Triangulation(points, simp, vals, tr)
+		np.testing.assert_array_equal(_shim.tri_eval(None, device, None, q), _shim.tri_eval(None, host, None, q))
 
 
 def test_tri_eval_ragged_equals_flat(gpu):

@@ -11,3 +11,5 @@ for n in (2000, 80000):
     for rep in range(4):
         t0 = time.perf_counter(); T = _shim.Triangulation(pts, tri.simplices, vals, tri.transform); t1 = time.perf_counter(); T.close(); t2 = time.perf_counter()
         print("n=%d nt=%d create %.2f ms destroy %.2f ms" % (n, len(tri.simplices), 1e3*(t1-t0), 1e3*(t2-t1)))
+        t0 = time.perf_counter(); T = _shim.Triangulation(pts, tri.simplices, vals, scipy_transform=True); t1 = time.perf_counter(); T.close()
+        print("   transform on the device: create %.2f ms" % (1e3*(t1-t0)))
