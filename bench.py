@@ -117,7 +117,9 @@ def build_workload(torch, shim, dev, n_pages, rank):
 	h, w = warps[0]["nodes"].shape[:2]
 	Hd, Wd = h * CELL, w * CELL
 	dense = torch.empty((Hd, Wd, 2), dtype=torch.float32, device=dev)
-	outs = torch.empty((n_pages, Hd, Wd), dtype=torch.uint8, device=dev)
+	# one allocation per dewarped page (a page of 6075 x 8075 bytes is an odd number of bytes long: packed pages would
+	# start at every alignment; K2 aligns its stores to the output whatever that is, its map loads follow when it can)
+	outs = [torch.empty((Hd, Wd), dtype=torch.uint8, device=dev) for _ in range(n_pages)]
 	return dict(base=base, pages=pages, warps=warps, polys=polys, dense=dense, outs=outs, Hd=Hd, Wd=Wd, h=h, w=w)
 
 

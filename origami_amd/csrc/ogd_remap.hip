@@ -45,14 +45,23 @@ static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, 
   constexpr int LX = TileShape<MapSrc>::LX, RPT = TileShape<MapSrc>::RPT;
   constexpr int TW = 4 * LX, TH = (64 / LX) * RPT;
   constexpr int LDSW = C == 1 ? 4096 : TileShape<MapSrc>::LDSW_MC;  // source window budget per wavefront
-  const int nbx = (Wd + TW - 1) / TW, nby = (Hd + TH - 1) / TH, nb = nbx * nby;
+  // sheared tiles (ogd_remap_lds.h:rl_shear): rows begin up to `reach` columns left of their tile's nominal origin
+  int step = 0, wrap = 0, bias = 0, reach = 0;
+  if (MapSrc::SHEAR && C == 1) {
+    step = (int)(((ds % 64) + 64) % 64);
+    if (step >= 32) step -= 64;
+    wrap = std::abs(step) * (TH - 1) >= 64;
+    bias = (wrap || step < 0) ? 64 : 0;
+    reach = 63 + bias + (wrap ? 31 : std::max(0, step * (TH - 1)));
+  }
+  const int nbx = (Wd + reach + TW - 1) / TW, nby = (Hd + TH - 1) / TH, nb = nbx * nby;
   const dim3 grid((nb + RL_WPB - 1) / RL_WPB), block(64 * RL_WPB);
   if (interp == OGD_INTER_LINEAR)
     hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_LINEAR, LX, RPT, LDSW, MapSrc>), grid, block,
-                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
+                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb, step, wrap, bias);
   else
     hipLaunchKernelGGL((remap_u8_wave_kernel<C, OGD_INTER_NEAREST, LX, RPT, LDSW, MapSrc>), grid, block,
-                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb);
+                       0, st, src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, nb, step, wrap, bias);
 }
 
 template <class MapSrc>

@@ -84,6 +84,7 @@ __device__ __forceinline__ void rl_wave_reduce_minmax(int& mn, int& mx) {
 
 // K2 proper: the dense map materialised in memory ([Hd][Wd] float2).
 struct MapGlobal {
+  static constexpr bool SHEAR = true;  // one-channel tiles are sheared onto the sectors of the output (see the kernel)
   const float* __restrict__ map;
   int Hd, Wd;
 
@@ -92,28 +93,28 @@ struct MapGlobal {
     return make_float2(p[0], p[1]);
   }
 
+  // Xr[r]: column of the lane's first pixel in row pass r (all equal unless the tile is sheared)
   template <int LX, int RPT>
-  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int, int, float, float,
-                                       bool& interior) const {
+  __device__ __forceinline__ bool load(int, const int (&Xr)[RPT], int Yb, float (&mv)[RPT][8], uint32_t*, int, int, int,
+                                       int, float, float, bool& interior) const {
     constexpr int RW = 64 / LX;
     interior = false;  // nothing is known about a map read from memory: always clamp
-    if (X + 4 <= Wd) {
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const rl_gf p = (rl_gf)map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + X) * 2;
+    for (int r = 0; r < RPT; ++r) {
+      const int Y = min(Yb + r * RW, Hd - 1), X = Xr[r];
+      if (X >= 0 && X + 4 <= Wd) {
+        const rl_gf p = (rl_gf)map + ((size_t)Y * Wd + X) * 2;
         const rl_f4 a = *(rl_gf4)p, b = *(rl_gf4)(p + 4);
         mv[r][0] = a.x; mv[r][1] = a.y; mv[r][2] = a.z; mv[r][3] = a.w;
         mv[r][4] = b.x; mv[r][5] = b.y; mv[r][6] = b.z; mv[r][7] = b.w;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r)
+      } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float2 v = at(min(X + k, Wd - 1), min(Yb + r * RW, Hd - 1));
+          const float2 v = at(min(max(X + k, 0), Wd - 1), Y);
           mv[r][2 * k] = v.x;
           mv[r][2 * k + 1] = v.y;
         }
+      }
     }
     return true;
   }
@@ -125,6 +126,7 @@ struct MapGlobal {
 // its own, because as a run-time test the compiler turns it into selects over both results).
 template <bool UNIT>
 struct MapNodesT {
+  static constexpr bool SHEAR = false;  // the map of a tile is built per tile column: rectangular tiles only
   const float2* __restrict__ nodes;
   int h, w;
   double inv_s;
@@ -146,8 +148,9 @@ struct MapNodesT {
   // Returns false (wave-uniform) when the sub-grid does not fit the slice (cells of a pixel or two): the
   // caller then takes the per-pixel path for the tile.
   template <int LX, int RPT>
-  __device__ __forceinline__ bool load(int X, int Yb, float (&mv)[RPT][8], uint32_t* lds, int lds_dwords,
-                                       int lane, int X0, int Y0, float xmax, float ymax, bool& interior) const {
+  __device__ __forceinline__ bool load(int X, const int (&)[RPT], int Yb, float (&mv)[RPT][8], uint32_t* lds,
+                                       int lds_dwords, int lane, int X0, int Y0, float xmax, float ymax,
+                                       bool& interior) const {
     constexpr int RW = 64 / LX, TW = 4 * LX, TH = RW * RPT;
     static_assert(TW <= 32 && TH <= 32, "one tile column per lane of the lower half-wave, one tile row per lane of the upper");
     constexpr int NP = 8;  // node sub-grid pitch: one node per lane (8 x 8)
@@ -237,19 +240,35 @@ struct MapNodesT {
 typedef MapNodesT<false> MapNodes;
 typedef MapNodesT<true> MapNodesUnit;
 
+// Sheared tiles (K2 proper, one channel).  A wavefront stores 4 * LX bytes per output row, and where those do not
+// begin on a 64-byte sector of the output ADDRESS every such store leaves two partial sectors for the memory
+// system to merge (tools/kbench, map-stream skeleton of this kernel on a 6075-byte pitch: 83 us, 79 us with
+// aligned segments).  So row rr of tile (bx, by) covers the columns [bx * TW - a, bx * TW - a + TW) with
+// a = sh0 + d(rr), a = (address of the tile row's first output row + rr * stride) mod 64 up to a multiple of 64:
+// sh0 comes from the tile row, d(rr) = rr * step while that stays within a sector's length (step = stride mod 64,
+// taken from [-32, 32)), else its residue in [-32, 32) — the rows of a tile then lie within 64 columns of each other
+// and the source window grows by that much at most.  Every row is still cut into consecutive TW-column pieces.
+__device__ __forceinline__ int rl_shear(int sh0, int step, int wrap, int rr) {
+  const int d = rr * step;
+  return sh0 + (wrap ? ((d + 32) & 63) - 32 : d);
+}
+
 // Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).
 template <int C, int INTERP, int LX, int RPT, class MapSrc>
 __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, int H, int W,
                                                ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
-                                               uint8_t* __restrict__ dst, ptrdiff_t ds, int X, int Yb) {
+                                               uint8_t* __restrict__ dst, ptrdiff_t ds, int X0, int Yb,
+                                               int sh0, int sh_step, int sh_wrap) {
   constexpr int RW = 64 / LX;
   // rolled loops: this rare path must not set the register budget (and with it the occupancy) of the kernel
 #pragma unroll 1
   for (int r = 0; r < RPT; ++r) {
     const int Y = Yb + r * RW;
     if (Y >= Hd) continue;
+    const int X = X0 - rl_shear(sh0, sh_step, sh_wrap, (threadIdx.x & 63) / LX + r * RW);
 #pragma unroll 1
     for (int k = 0; k < 4 && X + k < Wd; ++k) {
+      if (X + k < 0) continue;
       const float2 m = ms.at(X + k, Y);
       uint8_t o[C];
       sample_q<C, INTERP>(src, H, W, ss, quantize<INTERP>(m.x), quantize<INTERP>(m.y), o);
@@ -274,14 +293,15 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
 __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
     const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
-    uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+    uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb, int sh_step = 0, int sh_wrap = 0, int sh_bias = 0) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
+  constexpr bool SHEAR = MapSrc::SHEAR && C == 1;
   constexpr int TAPS = LIN ? 2 : 1;
   constexpr int SHIFT = LIN ? 5 : 0;
   constexpr int RW = 64 / LX;   // output rows per wave pass
   constexpr int TH = RW * RPT;  // tile height
   constexpr int TW = 4 * LX;    // tile width
-  constexpr int PF = ((TW * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
+  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
   constexpr int MAXROWS = LDSW / PF;
   // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
   constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
@@ -296,11 +316,26 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   const int by = t / nbx, bx = t - by * nbx;
   const int X = bx * TW + lx4;
   const int Yb = by * TH + ly;  // row of pass r: Yb + r * RW
+  int Xr[RPT];  // column of the lane's first pixel in row pass r
+  int sh0 = 0;
+  if (SHEAR) {
+    sh0 = (int)((reinterpret_cast<uintptr_t>(dst) + (ptrdiff_t)(by * TH) * ds) & 63) + sh_bias;
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      Xr[r] = X - rl_shear(sh0, sh_step, sh_wrap, ly + r * RW);
+      any |= Yb + r * RW < Hd && Xr[r] + 4 > 0 && Xr[r] < Wd;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // a tile past the ends of all its rows
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) Xr[r] = X;
+  }
   float mv[RPT][8];
   bool interior;  // wave-uniform: the clamp below cannot change any map value of this tile
-  if (!ms.template load<LX, RPT>(X, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH, (float)(W - 1), (float)(H - 1),
+  if (!ms.template load<LX, RPT>(X, Xr, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH, (float)(W - 1), (float)(H - 1),
                                  interior)) {  // wave-uniform
-    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb);
+    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb, sh0, sh_step, sh_wrap);
     return;
   }
 
@@ -349,7 +384,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   const int wbytes = (mxx + TAPS) * C - x0b;
   const int nrows = mxy + TAPS - mny;
   if (wbytes > PF || nrows > MAXROWS) {  // wave-uniform
-    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb);
+    remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb, sh0, sh_step, sh_wrap);
     return;
   }
 
@@ -471,9 +506,10 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
         for (int c = 0; c < C; ++c) o[k * C + c] = (uint32_t)p[c] << 16;
       }
     }
-    if (Y < Hd && X < Wd) {
-      uint8_t* d = dtile + (dlane + (uint32_t)(r * RW) * ds32);
-      if (X + 4 <= Wd) {
+    const int Xs = Xr[r];
+    if (Y < Hd && Xs < Wd && Xs + 4 > 0) {
+      uint8_t* d = dtile + (int)(dlane + (uint32_t)(r * RW) * ds32 + (uint32_t)((Xs - X) * C));
+      if (Xs >= 0 && Xs + 4 <= Wd) {
 #pragma unroll
         for (int j = 0; j < 4 * C; j += 4) {
           const uint32_t lo = __builtin_amdgcn_perm(o[j + 1], o[j], 0x0c0c0602u);
@@ -481,7 +517,9 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
           *reinterpret_cast<rl_u32u*>(d + j) = lo | hi;
         }
       } else {
-        for (int j = 0; j < (Wd - X) * C; ++j) d[j] = (uint8_t)(o[j] >> 16);
+#pragma unroll
+        for (int j = 0; j < 4 * C; ++j)
+          if ((unsigned)(Xs + j / C) < (unsigned)Wd) d[j] = (uint8_t)(o[j] >> 16);
       }
     }
   }

@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star): label maps / integer work bit-exact; uint8 imag
 grid within 1e-3 px (here: bit-exact); fp64 interpolation within 1e-9 (bit-exact away from shared
 triangle edges)."""
 
+import ctypes
+
 import numpy as np
 import pytest
 import scipy.interpolate
@@ -54,7 +56,6 @@ def test_grid_fill_random_shapes(gpu):
 def test_grid_fill_rows_into_any_8_byte_aligned_buffer(gpu, cell):
 	"""ogd_grid_fill_rows_dev: a band of rows written to wherever the caller points (K1a's spans begin on the
 	128-byte lines of the actual address: a buffer 8, 24 or 120 bytes past a line must give the same values)."""
-	import ctypes
 	lib = gpu.load()
 	rng = np.random.default_rng(cell)
 	h, w = 9, 47
@@ -154,6 +155,56 @@ def test_remap_strided_source_and_tiny_images(gpu):
 	m1 = rng.uniform(-1.5, 1.5, size=(9, 9, 2)).astype(np.float32)
 	np.testing.assert_array_equal(gpu.remap_u8(one, m1), ocv.remap_u8(one, m1))
 	np.testing.assert_array_equal(gpu.remap_u8(one, m1, 0), ocv.remap_u8(one, m1, 0))
+
+
+def test_remap_dev_into_any_stride_and_alignment(gpu):
+	"""K2 cuts every output row into pieces that begin on 64-byte sectors of the output ADDRESS (sheared tiles,
+	ogd_remap_lds.h:rl_shear): every residue of the row stride mod 64 (drifting rows as well as rows that wrap),
+	misaligned buffers, outputs narrower than a tile and wider than several; nothing outside the rows is written."""
+	lib = gpu.load()
+	rng = np.random.default_rng(64)
+	H, W = 120, 150
+	src = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+	cap = 64 * 1024
+	d_src, d_map, d_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_src), src.nbytes))
+	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_map), 277 * 41 * 8))
+	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_out), cap))
+	launches = 0
+	try:
+		gpu.check(lib.ogd_memcpy_h2d(d_src, src.ctypes.data, src.nbytes, None))
+		for Wd, Hd in [(1, 9), (3, 20), (63, 17), (64, 8), (65, 33), (200, 41), (277, 23)]:
+			yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+			m = np.stack([xx * (W / Wd) + 2 * np.sin(yy / 5), yy * (H / Hd) + 2 * np.cos(xx / 7)], -1)
+			m = np.ascontiguousarray((m + rng.normal(0, 0.4, m.shape)).astype(np.float32))
+			m[0, 0] = [-3, -3]
+			m[-1, -1] = [np.nan, 2]
+			gpu.check(lib.ogd_memcpy_h2d(d_map, m.ctypes.data, m.nbytes, None))
+			for interp in (ocv.INTER_LINEAR, ocv.INTER_NEAREST):
+				want = ocv.remap_u8(src, m, interp)
+				for extra in range(64 if interp == ocv.INTER_LINEAR else 8):
+					stride = Wd + extra
+					n = (Hd - 1) * stride + Wd
+					lead = (-d_out.value) % 64 + (0, 1, 37, 63, 4, 32)[extra % 6]
+					total = lead + n + 128
+					assert total <= cap
+					out = np.full(total, 0xEE, dtype=np.uint8)
+					gpu.check(lib.ogd_memcpy_h2d(d_out, out.ctypes.data, total, None))
+					gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, 1, W, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
+					gpu.check(lib.ogd_memcpy_d2h(out.ctypes.data, d_out, total, None))
+					gpu.check(lib.ogd_stream_sync(None))
+					launches += 1
+					msg = "Wd %d Hd %d stride %d lead %d interp %d" % (Wd, Hd, stride, lead, interp)
+					assert (out[:lead] == 0xEE).all() and (out[lead + n:] == 0xEE).all(), msg
+					rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, Wd), strides=(stride, 1))
+					np.testing.assert_array_equal(rows, want, err_msg=msg)
+					if extra:
+						gaps = np.lib.stride_tricks.as_strided(out[lead + Wd:], shape=(Hd - 1, extra), strides=(stride, 1))
+						assert (gaps == 0xEE).all(), msg
+	finally:
+		for d in (d_src, d_map, d_out):
+			lib.ogd_dev_free(d)
+	assert launches == 7 * 72
 
 
 def test_remap_label_map_through_scaled_grid(gpu):

@@ -37,6 +37,11 @@
 
 using namespace ogd;
 
+// the map source of K2 without the sheared tiles of the library's launch: the "wave ..." variants below
+struct MapGlobalPlain : MapGlobal {
+  static constexpr bool SHEAR = false;
+};
+
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 template <bool NT>
@@ -164,6 +169,87 @@ __global__ __launch_bounds__(256) void map_stream_tile(const float* __restrict__
       const uint32_t v = (uint32_t)(int)m[r][0].x | ((uint32_t)(int)m[r][0].z << 8) |
                          ((uint32_t)(int)m[r][1].x << 16) | ((uint32_t)(int)m[r][1].z << 24);
       st4<false>(dst + (ptrdiff_t)(Yb + r * RW) * ds + X, v);
+    }
+}
+
+// the same with the workgroup's output (4 neighbouring tiles of one tile row: 4 * TW bytes per row) collected in LDS
+// and written as 8-byte chunks aligned to the output ADDRESS: two partial 64-byte sectors per row and workgroup
+// instead of two per row and wavefront
+template <int LX, int RPT>
+__global__ __launch_bounds__(256) void map_stream_tile_wg(const float* __restrict__ map, int Hd, int Wd,
+                                                          uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx4) {
+  constexpr int RW = 64 / LX, TH = RW * RPT, TW = 4 * LX, RB = 4 * TW;
+  __shared__ __attribute__((aligned(16))) uint32_t tile[TH * RB / 4 + 4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int by = blockIdx.x / nbx4, bx4 = blockIdx.x - by * nbx4;
+  const int X0 = bx4 * RB;
+  const int X = X0 + wave * TW + (lane % LX) * 4, Yb = by * TH + lane / LX;
+  f4a8 m[RPT][2];
+  const int Xc = min(X, Wd - 4);
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const float* p = map + ((size_t)min(Yb + r * RW, Hd - 1) * Wd + Xc) * 2;
+    m[r][0] = ldmap<false>(p);
+    m[r][1] = ldmap<false>(p + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const uint32_t v = (uint32_t)(int)m[r][0].x | ((uint32_t)(int)m[r][0].z << 8) |
+                       ((uint32_t)(int)m[r][1].x << 16) | ((uint32_t)(int)m[r][1].z << 24);
+    tile[((lane / LX + r * RW) * RB + wave * TW + (lane % LX) * 4) >> 2] = v;
+  }
+  __syncthreads();
+  constexpr int CPR = RB / 8;          // full chunks per row
+  constexpr int TPR = 256 / TH;        // threads per row
+  const int row = threadIdx.x / TPR, j = threadIdx.x % TPR;
+  const int Y = by * TH + row;
+  if (Y >= Hd) return;
+  const int n = min(RB, Wd - X0);      // valid bytes of this row
+  uint8_t* a = dst + (ptrdiff_t)Y * ds + X0;
+  const int sg = (int)(reinterpret_cast<uintptr_t>(a) & 7);
+  const uint8_t* lrow = reinterpret_cast<const uint8_t*>(tile) + row * RB;
+  for (int c = j; c <= CPR; c += TPR) {
+    const int o = 8 * c - sg;          // row byte offset of the chunk
+    if (o >= 0 && o + 8 <= n) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(lrow + (o & ~3));
+      const uint32_t lo = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)o);
+      const uint32_t hi = __builtin_amdgcn_alignbyte(q[2], q[1], (uint32_t)o);
+      *reinterpret_cast<uint2*>(a + o) = make_uint2(lo, hi);
+    } else {
+      for (int b = max(o, 0); b < min(o + 8, n); ++b) a[b] = lrow[b];
+    }
+  }
+}
+
+// the same with every row of a tile moved left until its first output byte stands on a 64-byte sector of the
+// output ADDRESS (a sheared tile; SHEAR_MAP: until its first map value stands on a 128-byte line instead)
+template <int LX, int RPT, bool SHEAR_MAP>
+__global__ __launch_bounds__(256) void map_stream_tile_shear(const float* __restrict__ map, int Hd, int Wd,
+                                                             uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb) {
+  constexpr int RW = 64 / LX, TH = RW * RPT, TW = 4 * LX;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= nb) return;
+  const int by = t / nbx, bx = t - by * nbx;
+  const int Yb = by * TH + lane / LX;
+  f4a8 m[RPT][2];
+  int Xr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int Y = min(Yb + r * RW, Hd - 1);
+    const int a = SHEAR_MAP ? (int)(((reinterpret_cast<uintptr_t>(map) >> 3) + (size_t)Y * Wd + bx * TW) & 15)
+                            : (int)((reinterpret_cast<uintptr_t>(dst) + (size_t)Y * ds + bx * TW) & 63);
+    Xr[r] = bx * TW + (lane % LX) * 4 - a;
+    const float* p = map + ((size_t)Y * Wd + min(max(Xr[r], 0), Wd - 4)) * 2;
+    m[r][0] = ldmap<false>(p);
+    m[r][1] = ldmap<false>(p + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+    if (Yb + r * RW < Hd && Xr[r] >= 0 && Xr[r] + 4 <= Wd) {
+      const uint32_t v = (uint32_t)(int)m[r][0].x | ((uint32_t)(int)m[r][0].z << 8) |
+                         ((uint32_t)(int)m[r][1].x << 16) | ((uint32_t)(int)m[r][1].z << 24);
+      st4<false>(dst + (ptrdiff_t)(Yb + r * RW) * ds + Xr[r], v);
     }
 }
 
@@ -322,10 +408,15 @@ int main(int argc, char** argv) {
   float* d_nodes;
   CK(hipMalloc(&d_nodes, nodes.size() * 4));
   CK(hipMemcpy(d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMalloc(&c.map, (size_t)c.Hd * c.Wd * 8));
+  // KB_MAP_OFF (pixels of 8 B) / KB_DST_OFF (bytes): buffers moved off their 128-byte alignment
+  const int map_off = getenv("KB_MAP_OFF") ? atoi(getenv("KB_MAP_OFF")) : 0;
+  const int dst_off = getenv("KB_DST_OFF") ? atoi(getenv("KB_DST_OFF")) : 0;
+  CK(hipMalloc(&c.map, (size_t)c.Hd * c.Wd * 8 + 1024));
+  c.map += 2 * map_off;
   CK(hipMalloc(&c.src, page.size()));
   CK(hipMemcpy(c.src, page.data(), page.size(), hipMemcpyHostToDevice));
-  CK(hipMalloc(&c.dst, (size_t)c.Hd * c.Wd));
+  CK(hipMalloc(&c.dst, (size_t)c.Hd * c.Wd + 1024));
+  c.dst += dst_off;
   OK(ogd_grid_fill_dev(d_nodes, h, w, cell, 1.f, 1.f, c.map, nullptr));
   CK(hipDeviceSynchronize());
   c.h_ref.resize((size_t)c.Hd * c.Wd);
@@ -476,20 +567,43 @@ int main(int argc, char** argv) {
     const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
     const int nbx2 = (c.Wd + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;                 \
     run(c, "wave LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                            \
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobal>), dim3((nb + RL_WPB - 1) / RL_WPB),    \
-                         dim3(64 * RL_WPB), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd},  \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobalPlain>), dim3((nb + RL_WPB - 1) / RL_WPB),    \
+                         dim3(64 * RL_WPB), 0, 0, c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobalPlain{{c.map, c.Hd, c.Wd}},  \
                          c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                                                                    \
     });                                                                                                 \
   }
   {  // nearest sampling through the same map: the memory side of K2 with a fraction of its integer work
     const int nbx2 = (c.Wd + 63) / 64, nby = (c.Hd + 7) / 8, nb = nbx2 * nby;
     run(c, "wave LX=16 RPT=2 nearest", [&] {
-      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 0, 16, 2, 4096, MapGlobal>), dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0,
-                         c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd}, c.Hd, c.Wd, c.dst,
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 0, 16, 2, 4096, MapGlobalPlain>), dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0,
+                         c.src, c.H, c.W, (ptrdiff_t)c.W, MapGlobalPlain{{c.map, c.Hd, c.Wd}}, c.Hd, c.Wd, c.dst,
                          (ptrdiff_t)c.Wd, nbx2, nb);
     }, false);
   }
   WAVE_VARIANT(16, 2, 4096)
+  // sheared tiles (what the library launches for one channel), other shapes
+#define WAVE_SHEAR_VARIANT(LX, RPT, LDSW)                                                               \
+  {                                                                                                     \
+    const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
+    int step = (int)(c.Wd % 64);                                                                        \
+    if (step >= 32) step -= 64;                                                                         \
+    const int wrap = std::abs(step) * (th - 1) >= 64, bias = (wrap || step < 0) ? 64 : 0;               \
+    const int reach = 63 + bias + (wrap ? 31 : std::max(0, step * (th - 1)));                           \
+    const int nbx2 = (c.Wd + reach + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;         \
+    run(c, "wave sheared LX=" #LX " RPT=" #RPT " ldsw=" #LDSW, [&] {                                    \
+      hipLaunchKernelGGL((remap_u8_wave_kernel<1, 1, LX, RPT, LDSW, MapGlobal>),                        \
+                         dim3((nb + RL_WPB - 1) / RL_WPB), dim3(64 * RL_WPB), 0, 0, c.src, c.H, c.W,    \
+                         (ptrdiff_t)c.W, MapGlobal{c.map, c.Hd, c.Wd}, c.Hd, c.Wd, c.dst,               \
+                         (ptrdiff_t)c.Wd, nbx2, nb, step, wrap, bias);                                  \
+    });                                                                                                 \
+  }
+  WAVE_SHEAR_VARIANT(16, 2, 4096)
+  WAVE_SHEAR_VARIANT(16, 1, 4096)
+  WAVE_SHEAR_VARIANT(16, 4, 4096)
+  WAVE_SHEAR_VARIANT(32, 1, 4096)
+  WAVE_SHEAR_VARIANT(32, 2, 4096)
+  WAVE_SHEAR_VARIANT(16, 2, 3072)
+  WAVE_SHEAR_VARIANT(16, 2, 5120)
   WAVE_VARIANT(16, 2, 8192)
   WAVE_VARIANT(16, 4, 4096)
   WAVE_VARIANT(8, 2, 4096)
@@ -538,6 +652,28 @@ int main(int argc, char** argv) {
     }, false);                                                                                          \
   }
   STREAM_TILE(16, 2)
+#define STREAM_TILE_WG(LX, RPT)                                                                        \
+  {                                                                                                     \
+    const int rb = 16 * LX, th = (64 / LX) * RPT;                                                       \
+    const int nbx4 = (c.Wd + rb - 1) / rb, nby = (c.Hd + th - 1) / th;                                  \
+    run(c, "map-stream tile wg-store LX=" #LX " RPT=" #RPT, [&] {                                       \
+      hipLaunchKernelGGL((map_stream_tile_wg<LX, RPT>), dim3(nbx4 * nby), dim3(256), 0, 0, c.map, c.Hd, \
+                         c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx4);                                           \
+    }, false);                                                                                          \
+  }
+  STREAM_TILE_WG(16, 2)
+#define STREAM_TILE_SHEAR(LX, RPT, SM)                                                                  \
+  {                                                                                                     \
+    const int tw = 4 * LX, th = (64 / LX) * RPT;                                                        \
+    const int nbx2 = (c.Wd + 63 + tw - 1) / tw, nby = (c.Hd + th - 1) / th, nb = nbx2 * nby;            \
+    run(c, "map-stream tile shear LX=" #LX " RPT=" #RPT " map=" #SM, [&] {                              \
+      hipLaunchKernelGGL((map_stream_tile_shear<LX, RPT, SM>), dim3((nb + 3) / 4), dim3(256), 0, 0,     \
+                         c.map, c.Hd, c.Wd, c.dst, (ptrdiff_t)c.Wd, nbx2, nb);                          \
+    }, false);                                                                                          \
+  }
+  STREAM_TILE_SHEAR(16, 2, false)
+  STREAM_TILE_SHEAR(16, 2, true)
+  STREAM_TILE_WG(16, 4)
   STREAM_TILE(16, 4)
   STREAM_TILE(32, 2)
   STREAM_TILE(32, 4)
