@@ -207,6 +207,61 @@ def test_remap_dev_into_any_stride_and_alignment(gpu):
 	assert launches == 7 * 72
 
 
+def test_remap_dev_random_shapes_strides_and_maps(gpu):
+	"""Eight hundred seeded random cases through ogd_remap_u8_dev (one channel: the sheared tiles) against the oracle,
+	bit for bit: source and output sizes, output strides and misalignments, both interpolations; maps that are smooth,
+	slanted, sheared beyond the LDS window, incoherent or folded with a NaN; guard bytes around and between the rows."""
+	lib = gpu.load()
+	rng = np.random.default_rng(7)
+	cap_src, cap_map, cap_out = 1 << 20, 8 << 20, 2 << 20
+	d_src, d_map, d_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+	for d, n in ((d_src, cap_src), (d_map, cap_map), (d_out, cap_out)):
+		gpu.check(lib.ogd_dev_alloc(ctypes.byref(d), n))
+	for case in range(800):
+		H, W = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+		Hd, Wd = int(rng.integers(1, 120)), int(rng.integers(1, 1100))
+		if rng.random() < 0.1:
+			Wd = int(rng.integers(1, 70))
+		stride = Wd + int(rng.choice([0, 0, 1, 5, 27, 32, 59, 64, int(rng.integers(0, 200))]))
+		lead = int(rng.integers(0, 130))
+		interp = int(rng.choice([1, 1, 1, 0]))
+		src = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+		yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+		kind = int(rng.integers(0, 5))
+		if kind == 0:
+			m = np.stack([xx * (W / Wd), yy * (H / Hd)], -1) + rng.normal(0, 0.5, (Hd, Wd, 2))
+		elif kind == 1:
+			m = np.stack([xx + 0.04 * yy + rng.uniform(-3, 3), yy - 0.03 * xx + rng.uniform(-3, 3)], -1)
+		elif kind == 2:
+			m = np.stack([xx * 3.1 - yy * 2.2, yy * 2.7 + xx * 1.1], -1)
+		elif kind == 3:
+			m = rng.uniform([-W, -H], [2 * W, 2 * H], (Hd, Wd, 2))
+		else:
+			m = np.stack([np.abs(W / 2 - xx), np.abs(H / 2 - yy * 2)], -1)
+			m[rng.integers(0, Hd), rng.integers(0, Wd)] = [np.nan, 1e30]
+		m = np.ascontiguousarray(m.astype(np.float32))
+		n = (Hd - 1) * stride + Wd
+		total = lead + n + 200
+		assert src.nbytes <= cap_src and m.nbytes <= cap_map and total <= cap_out
+		want = ocv.remap_u8(src, m, interp)
+		out = np.full(total, 0xA5, dtype=np.uint8)
+		gpu.check(lib.ogd_memcpy_h2d(d_src, src.ctypes.data, src.nbytes, None))
+		gpu.check(lib.ogd_memcpy_h2d(d_map, m.ctypes.data, m.nbytes, None))
+		gpu.check(lib.ogd_memcpy_h2d(d_out, out.ctypes.data, total, None))
+		gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, 1, W, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
+		gpu.check(lib.ogd_memcpy_d2h(out.ctypes.data, d_out, total, None))
+		gpu.check(lib.ogd_stream_sync(None))
+		msg = "case %d: src %dx%d out %dx%d stride %d lead %d interp %d kind %d" % (case, W, H, Wd, Hd, stride, lead, interp, kind)
+		rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, Wd), strides=(stride, 1))
+		np.testing.assert_array_equal(rows, want, err_msg=msg)
+		guard = np.ones(total, dtype=bool)
+		for y in range(Hd):
+			guard[lead + y * stride: lead + y * stride + Wd] = False
+		assert (out[guard] == 0xA5).all(), "wrote outside its rows, " + msg
+	for d in (d_src, d_map, d_out):
+		lib.ogd_dev_free(d)
+
+
 def test_remap_label_map_through_scaled_grid(gpu):
 	"""layout.py:172-182: nearest remap of a label map through the page grid scaled to label size."""
 	rng = np.random.default_rng(11)
