@@ -3,7 +3,8 @@
 // (MapNodes: the fused K1a + K2 of Dewarper.dewarped / dewarp_image, ref: dewarp.py:608-627).
 //
 // Every wavefront owns a TW x TH tile of the output (TW = 4 * LX pixels, TH = (64 / LX) * RPT rows; the
-// library launches 64 x 8) and a private slice of LDS, so there is no workgroup barrier anywhere:
+// library launches 64 x 8; K2 proper on one channel shears the tile so that each of its rows begins on a 64-byte
+// sector of the output, see rl_shear) and a private slice of LDS, so there is no workgroup barrier anywhere:
 //   1. every lane loads the map of its 4 * RPT pixels (all loads issued before any use) and quantises
 //      it to fixed-point tap coordinates, clamped to the image plus a two-pixel zero border;
 //   2. the wavefront reduces the bounding box of those taps (packed int16 min / max over DPP);
