@@ -516,6 +516,15 @@ int main(int argc, char** argv) {
     run(c, "K1a+K2    lines TW=" #TW " TR=" #TR " threads=" #NTH, [&] { k1a(); lib(); });                 \
   }
   LINES_VARIANT(496, 8, 256)
+  {  // plain instead of non-temporal stores
+    auto k1a = [&] {
+      hipLaunchKernelGGL((grid_fill_lines_kernel<496, 8, false, 256>), dim3((c.Wd + 15 + 495) / 496, (c.Hd + 7) / 8),
+                         dim3(256), 0, 0, (const float2*)d_nodes, h, w, 1.0 / cell, 1.f, 1.f, (float2*)c.map, 0,
+                         c.Hd, c.Wd);
+    };
+    run(c, "K1a alone lines TW=496 TR=8 threads=256 plain stores", k1a, false);
+    run(c, "K1a+K2    lines TW=496 TR=8 threads=256 plain stores", [&] { k1a(); lib(); });
+  }
   LINES_VARIANT(496, 8, 512)
   LINES_VARIANT(496, 8, 1024)
   LINES_VARIANT(496, 4, 1024)
