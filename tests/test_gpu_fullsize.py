@@ -2,6 +2,8 @@
 the CPU oracle (bit-exact), plus size-independent properties (identity map, tiling invariance, linearity of
 the transformer on affine grids)."""
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,27 @@ def test_config2_broadsheet_gray_page_bit_exact(gpu):
 	np.testing.assert_array_equal(got, want)  # bar: +-1 LSB on 99.9 %; here every pixel
 	np.testing.assert_array_equal(gpu.dewarp_u8(page, nodes, 25), want)  # fused path, same bytes
 	assert (got > 0).mean() > 0.9
+	# the same page into rows of a padded pitch in a buffer off every alignment (K2's sheared tiles drift differently)
+	lib = gpu.load()
+	Hd, Wd = want.shape
+	pitch, lead = 6144 + 27, 37
+	out = np.full(lead + Hd * pitch + 64, 0x5A, dtype=np.uint8)
+	d_src, d_map, d_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+	for d, n in ((d_src, page.nbytes), (d_map, dense.nbytes), (d_out, out.nbytes)):
+		gpu.check(lib.ogd_dev_alloc(ctypes.byref(d), n))
+	try:
+		gpu.check(lib.ogd_memcpy_h2d(d_src, page.ctypes.data, page.nbytes, None))
+		gpu.check(lib.ogd_memcpy_h2d(d_map, dense.ctypes.data, dense.nbytes, None))
+		gpu.check(lib.ogd_memcpy_h2d(d_out, out.ctypes.data, out.nbytes, None))
+		gpu.check(lib.ogd_remap_u8_dev(d_src, PAGE[1], PAGE[0], 1, PAGE[0], d_map, Hd, Wd, d_out.value + lead, pitch, 1, None))
+		gpu.check(lib.ogd_memcpy_d2h(out.ctypes.data, d_out, out.nbytes, None))
+		gpu.check(lib.ogd_stream_sync(None))
+	finally:
+		for d in (d_src, d_map, d_out):
+			lib.ogd_dev_free(d)
+	rows = out[lead:lead + Hd * pitch].reshape(Hd, pitch)
+	np.testing.assert_array_equal(rows[:, :Wd], want)
+	assert (rows[:-1, Wd:] == 0x5A).all() and (out[:lead] == 0x5A).all() and (out[lead + (Hd - 1) * pitch + Wd:] == 0x5A).all()
 
 
 def test_config4_rgb_page_and_label_map_fine_grid_bit_exact(gpu):
