@@ -96,11 +96,18 @@ class ZipReader:
 			raise zipfile.BadZipFile("Bad CRC-32 for file %r" % name)
 		return data
 
+	def _small_members(self):
+		"""True if the archive's deflated members are a few hundred bytes each (a page's contours: 400 members of
+		160 bytes).  The library's inflate builds 10-bit tables with literal pairs per block, which pays from a few
+		kilobytes on (a 600 KB data.npy: 1 ms against zlib's 4); on such members zlib's leaner set-up wins
+		(tools/zip_read_time.py: 1.1 against 2.4 ms for the archive)."""
+		sizes = [m[3] for m in self._members.values() if m[1] == 8]
+		return bool(sizes) and sum(sizes) < 2048 * len(sizes)
+
 	def items(self):
-		"""(name, data) of every member.  All members are inflated and checked in ONE call into libogdewarp
-		(ogd_inflate_many): a contours archive holds hundreds of members of a kilobyte, and a Python-level call per
-		member costs more than inflating it."""
-		if self._zf is not None or not self._members:
+		"""(name, data) of every member.  Archives of substantial members are inflated and checked in ONE call into
+		libogdewarp (ogd_inflate_many); archives of many tiny members go member by member through zlib."""
+		if self._zf is not None or not self._members or self._small_members():
 			for name in self._members:
 				yield name, self.read(name)
 			return
