@@ -253,75 +253,47 @@ def bind_to_gpu_numa_node(torch, local_rank):
 		return None
 
 
-def pipeline_leg(torch, lib, check, wl, n_jobs, barrier, streams, slots=3):
-	"""BASELINE.json configs[2] per GPU: `n_jobs` page jobs drawn by cycling the batch's
-	pages from a PINNED HOST ring -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + the page's contour rings (K3) ->
-	D2H of the dewarped page and the warped contours, on three streams (upload / kernels / download) with
-	`slots` device slots.  The last job's page is checked against the resident path's output.  Returns
-	(elapsed seconds of this rank, bytes up, bytes down).
-	streams = (upload, kernels, download): the process must not hold more streams than the GPU_MAX_HW_QUEUES = 4
-	hardware queues it gets — with a fifth stream two of them share a queue, upload and download take turns and
-	the leg runs at a third of the PCIe rate (measured: 4.2 instead of 1.6 ms/page)."""
+def pipeline_leg(torch, wl, n_jobs, barrier, streams, slots=3):
+	"""BASELINE.json configs[2] per GPU through the PRODUCT's pipeline class
+	(origami_amd/pipeline.py:PagePipeline): `n_jobs` page jobs drawn by cycling the batch's pages from a PINNED HOST
+	ring -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + the page's contour rings (K3) -> D2H of the dewarped page and
+	the warped contours, on three streams (upload / kernels / download) with `slots` device slots and at most
+	`slots` jobs in flight.  The last job's page is checked against the resident path's output.  Returns (elapsed
+	seconds of this rank, bytes up, bytes down).
+	streams = (upload, kernels, download) raw hipStream_t values: the process must not hold more streams than the
+	GPU_MAX_HW_QUEUES = 4 hardware queues it gets — with a fifth stream two of them share a queue, upload and
+	download take turns and the leg runs at a third of the PCIe rate (measured: 4.2 instead of 1.6 ms/page)."""
+	from origami_amd import pinned
+	from origami_amd.pipeline import DeviceArray, PageJob, PagePipeline
 	W, H = PAGE
-	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
+	Hd, Wd = wl["Hd"], wl["Wd"]
 	n_pages = wl["pages"].shape[0]
-	dev = wl["pages"].device
-	host_in = torch.empty((n_pages, H, W), dtype=torch.uint8, pin_memory=True)
-	host_in.copy_(wl["pages"])
-	host_out = torch.empty((slots + 1, Hd, Wd), dtype=torch.uint8, pin_memory=True)
-	max_pts = max(p["n"] for p in wl["polys"])
-	host_pts = torch.empty((slots + 1, max_pts, 2), dtype=torch.float64, pin_memory=True)
-	d_in = torch.empty((slots, H, W), dtype=torch.uint8, device=dev)
-	d_out = torch.empty((slots, Hd, Wd), dtype=torch.uint8, device=dev)
-	s_in, s_k, s_out = streams
-	ev_in = [torch.cuda.Event() for _ in range(slots)]
-	ev_k = [torch.cuda.Event() for _ in range(slots)]
-	ev_out = [torch.cuda.Event() for _ in range(slots)]
-	kstream = ctypes.c_void_p(s_k.cuda_stream)
+	host_in = pinned.empty((n_pages, H, W), np.uint8)  # the pinned host ring of page scans
+	torch.from_numpy(host_in).copy_(wl["pages"])
+	jobs = []
+	for p in range(n_pages):
+		wp, poly = wl["warps"][p % len(wl["warps"])], wl["polys"][p]
+		rings = (wp["tf"], DeviceArray(poly["q"].data_ptr(), (poly["n"], 2)),
+			DeviceArray(poly["off"].data_ptr(), (poly["nrings"] + 1,)))
+		jobs.append(PageJob(
+			host_in[p], DeviceArray(wp["nodes_d"].data_ptr(), wp["nodes"].shape), CELL, rings=rings, tag=p))
 
-	queued = [False] * slots
+	with PagePipeline(slots=slots, streams=streams) as pipe:
+		def run(n):
+			last = None
+			for result in pipe.map(jobs[j % n_pages] for j in range(n)):
+				last = result  # the consumer takes delivery (and drops the previous page)
+			return last
 
-	def run(n):
-		for j in range(n):
-			p, sl, ho = j % n_pages, j % slots, j % (slots + 1)
-			wp, poly = wl["warps"][p % len(wl["warps"])], wl["polys"][p]
-			# The host takes delivery of the slot's previous job before it queues the next one (a worker does: it
-			# hands the page on), so at most `slots` jobs are in flight.  With all jobs queued at once the same loop
-			# runs at 2.4 - 5.6 ms/page instead of 1.02: the copies of many queued jobs take turns on the engines
-			# (profiles/r02/q_pipeline_copy_durations.txt shows downloads of 3.8 - 6.9 ms between ones of 1.0).
-			if queued[sl]:
-				ev_out[sl].synchronize()
-			queued[sl] = True
-			with torch.cuda.stream(s_in):
-				s_in.wait_event(ev_k[sl])  # the slot's previous kernel has read d_in[sl]
-				d_in[sl].copy_(host_in[p], non_blocking=True)
-				ev_in[sl].record(s_in)
-			s_k.wait_event(ev_in[sl])
-			s_k.wait_event(ev_out[sl])  # the slot's previous download has read d_out[sl] / the page's contours
-			check(lib.ogd_dewarp_u8_dev(
-				d_in[sl].data_ptr(), H, W, 1, W, wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0,
-				d_out[sl].data_ptr(), Wd, 1, kstream))
-			check(lib.ogd_tri_eval_ragged_dev(
-				wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
-				poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), kstream))
-			ev_k[sl].record(s_k)
-			with torch.cuda.stream(s_out):
-				s_out.wait_event(ev_k[sl])
-				host_out[ho].copy_(d_out[sl], non_blocking=True)
-				host_pts[ho, :poly["n"]].copy_(poly["out"], non_blocking=True)
-				ev_out[sl].record(s_out)
-		torch.cuda.synchronize()
-
-	# Warm-up: one whole cycle over the host ring (the copy engines take some 60 pages to reach their rate:
-	# tools/pipeline_segments.py, profiles/r02/q_pipeline_warmup.log); configs[2] is a queue of 10 000 jobs.
-	run(max(2 * slots, n_pages))
-	barrier()
-	t0 = time.perf_counter()
-	run(n_jobs)
-	elapsed = time.perf_counter() - t0
-	barrier()
-	last = (n_jobs - 1) % n_pages
-	if not torch.equal(host_out[(n_jobs - 1) % (slots + 1)], wl["outs"][last].cpu()):
+		# Warm-up: one whole cycle over the host ring (the copy engines take some 60 pages to reach their rate:
+		# tools/pipeline_segments.py, profiles/r02/q_pipeline_warmup.log); configs[2] is a queue of 10 000 jobs.
+		run(max(2 * slots, n_pages))
+		barrier()
+		t0 = time.perf_counter()
+		last = run(n_jobs)
+		elapsed = time.perf_counter() - t0
+		barrier()
+	if not np.array_equal(last.page, wl["outs"][last.tag].cpu().numpy()):
 		raise SystemExit("bench: pipeline output differs from the resident path")
 	up = n_jobs * H * W
 	down = n_jobs * Hd * Wd + sum(wl["polys"][j % n_pages]["n"] for j in range(n_jobs)) * 16
@@ -452,8 +424,9 @@ def main():
 				torch.cuda.synchronize()
 		n_jobs = args.pipeline_jobs or 2 * args.pages
 		# kernels on the stream the timed steps used, uploads on their side stream, downloads on a third
+		third = torch.cuda.Stream()
 		p_elapsed, up, down = pipeline_leg(
-			torch, lib, check, wl, n_jobs, barrier, (side, torch.cuda.current_stream(), torch.cuda.Stream()))
+			torch, wl, n_jobs, barrier, (side.cuda_stream, torch.cuda.current_stream().cuda_stream, third.cuda_stream))
 		t = torch.tensor([p_elapsed], dtype=torch.float64, device=dev)
 		if world > 1:
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -508,7 +481,7 @@ def main():
 		if pipeline is not None:
 			pe = pipeline["elapsed"]
 			line["pipeline"] = {
-				"what": "configs[2] (SURVEY 8d ii): %d page jobs per GPU cycled from a pinned host ring of the batch's %d pages -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + K3 -> D2H of page and contours, 3 streams / 3 device slots per GPU, at most 3 jobs in flight; barrier + max over ranks; PCIe-inclusive, never `value`" % (
+				"what": "configs[2] (SURVEY 8d ii) through the product's origami_amd.pipeline.PagePipeline: %d page jobs per GPU cycled from a pinned host ring of the batch's %d pages -> H2D -> fused dewarp (ogd_dewarp_u8_dev) + K3 -> D2H of page and contours, 3 streams / 3 device slots per GPU, at most 3 jobs in flight; barrier + max over ranks; PCIe-inclusive, never `value`" % (
 					pipeline["n_jobs"], args.pages),
 				"value": round(world * pipeline["n_jobs"] * Hd * Wd / 1e6 / pe, 1), "unit": "MP/s",
 				"ms_per_page_per_gpu": round(pe / pipeline["n_jobs"] * 1e3, 4),

@@ -56,6 +56,36 @@ int ogd_dev_free(void* dptr);
 int ogd_memcpy_h2d(void* dptr, const void* hptr, size_t bytes, void* stream);
 int ogd_memcpy_d2h(void* hptr, const void* dptr, size_t bytes, void* stream);
 int ogd_stream_sync(void* stream);
+/* Strided forms (rows of `width` bytes, pitches in bytes), asynchronous on `stream` like the two above. */
+int ogd_memcpy2d_h2d(void* dptr, size_t dpitch, const void* hptr, size_t hpitch, size_t width, size_t rows,
+                     void* stream);
+int ogd_memcpy2d_d2h(void* hptr, size_t hpitch, const void* dptr, size_t dpitch, size_t width, size_t rows,
+                     void* stream);
+/* Free / total device memory of the bound GPU (hipMemGetInfo). */
+int ogd_mem_info(size_t* free_bytes, size_t* total_bytes);
+
+/* ---- what a caller needs to overlap page copies with kernels (no reference counterpart) ------------
+ * The reference opens and remaps one page at a time on the CPU (ref: origami/batch/core/io.py:275-280 ->
+ * origami/core/page.py:82-88) and gets its parallelism from a process pool (ref: origami/batch/core/
+ * processor.py:476-493).  On a GPU a broadsheet page is 48 MB up and 49 MB down for 0.07 ms of kernel, so the
+ * page rate is the PCIe rate — if copies come from PINNED host memory (56 GB/s against 14 GB/s from pageable
+ * memory) and run on streams of their own beside the kernels.  origami_amd/pipeline.py builds its page pipeline
+ * (upload / kernel / download streams, N device slots) from these and the *_dev entry points.
+ * ogd_host_alloc: page-locked host memory (hipHostMalloc); every host-buffer entry point also runs at the pinned
+ * rate when handed such buffers.  Streams are created non-blocking (they do not synchronise with the null stream
+ * the host-buffer entry points use).  A process gets GPU_MAX_HW_QUEUES (4) hardware queues: more streams than
+ * that share queues and their copies take turns.  Events: timing = 0 creates them with timing disabled. */
+int ogd_host_alloc(void** hptr, size_t bytes);
+int ogd_host_free(void* hptr);
+int ogd_stream_create(void** stream);
+int ogd_stream_destroy(void* stream);
+int ogd_stream_wait_event(void* stream, void* event);
+int ogd_event_create(void** event, int timing);
+int ogd_event_destroy(void* event);
+int ogd_event_record(void* event, void* stream);
+int ogd_event_sync(void* event);
+int ogd_event_query(void* event, int* done);
+int ogd_event_elapsed_ms(void* start, void* stop, float* ms);
 
 /* ---- K1a: dense sampling grid -------------------------------------------------------------
  * ref: origami/core/dewarp.py:522-523  (cv2.resize(grid[:, :, c], (w*s, h*s), INTER_LINEAR) x2)

@@ -43,6 +43,20 @@ SIGNATURES = {
 	"ogd_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 	"ogd_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 	"ogd_stream_sync": (c_int, [c_void_p]),
+	"ogd_memcpy2d_h2d": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+	"ogd_memcpy2d_d2h": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+	"ogd_mem_info": (c_int, [POINTER(c_size_t), POINTER(c_size_t)]),
+	"ogd_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+	"ogd_host_free": (c_int, [c_void_p]),
+	"ogd_stream_create": (c_int, [POINTER(c_void_p)]),
+	"ogd_stream_destroy": (c_int, [c_void_p]),
+	"ogd_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+	"ogd_event_create": (c_int, [POINTER(c_void_p), c_int]),
+	"ogd_event_destroy": (c_int, [c_void_p]),
+	"ogd_event_record": (c_int, [c_void_p, c_void_p]),
+	"ogd_event_sync": (c_int, [c_void_p]),
+	"ogd_event_query": (c_int, [c_void_p, POINTER(c_int)]),
+	"ogd_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
 	"ogd_grid_fill": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
 	"ogd_grid_fill_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
 	"ogd_grid_fill_rows_dev": (c_int, [
@@ -182,6 +196,13 @@ def _c(a, dtype):
 	return np.ascontiguousarray(a, dtype=dtype)
 
 
+def _pixels_out(shape):
+	"""Host array for page pixels coming back from the device: pinned memory (origami_amd.pinned — the copy runs at
+	the link's rate instead of a quarter of it, and the array can go straight back up), pageable without a GPU."""
+	from . import pinned
+	return pinned.empty_if_available(shape, np.uint8)
+
+
 # ---- K1a ------------------------------------------------------------------------------------------
 
 def grid_fill(nodes, cell, sx=1.0, sy=1.0):
@@ -239,7 +260,7 @@ def remap_u8(src, map_xy, interpolation=INTER_LINEAR):
 		raise ValueError("map must have shape (Hd, Wd, 2)")
 	H, W, C = src.shape
 	Hd, Wd = map_xy.shape[:2]
-	dst = np.empty((Hd, Wd, C), dtype=np.uint8)
+	dst = _pixels_out((Hd, Wd, C))
 	check(load().ogd_remap_u8(
 		_ptr(src), H, W, C, src.strides[0], _ptr(map_xy), Hd, Wd, _ptr(dst), dst.strides[0],
 		int(interpolation)))
@@ -252,7 +273,7 @@ def dewarp_u8(src, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
 	nodes = _c(nodes, np.float32)
 	H, W, C = src.shape
 	h, w = nodes.shape[:2]
-	dst = np.empty((h * cell, w * cell, C), dtype=np.uint8)
+	dst = _pixels_out((h * cell, w * cell, C))
 	check(load().ogd_dewarp_u8(
 		_ptr(src), H, W, C, src.strides[0], _ptr(nodes), h, w, int(cell), float(sx), float(sy),
 		_ptr(dst), dst.strides[0], int(interpolation)))
@@ -350,7 +371,7 @@ def jpeg_decode_gray(data):
 	H, W, nc, ok = jpeg_header(data)
 	if not ok:
 		return None
-	out = np.empty((H, W), dtype=np.uint8)
+	out = _pixels_out((H, W))
 	status = load().ogd_jpeg_decode_gray(_ptr(buf), buf.size, _ptr(out), H, W, out.strides[0])
 	if status in (ERR_UNSUPPORTED, ERR_RUNTIME):  # ERR_RUNTIME: truncated scan — PIL decides what to make of it
 		return None
@@ -412,7 +433,7 @@ class DevicePage:
 	def dewarp(self, nodes, cell, sx=1.0, sy=1.0, interpolation=INTER_LINEAR):
 		nodes = _c(nodes, np.float32)
 		h, w = nodes.shape[:2]
-		dst = np.empty((h * cell, w * cell, self.shape[2]), dtype=np.uint8)
+		dst = _pixels_out((h * cell, w * cell, self.shape[2]))
 		check(load().ogd_page_dewarp_u8(
 			self.handle, _ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(dst), dst.strides[0],
 			int(interpolation)))
@@ -752,7 +773,7 @@ def png_decode(data):
 	"""(H, W) or (H, W, 3) uint8 pixels of a PNG file's bytes, as np.array(PIL.Image.open(...)) gives them."""
 	data = bytes(data)
 	w, h, c = png_info(data)
-	out = np.empty((h, w) if c == 1 else (h, w, c), dtype=np.uint8)
+	out = _pixels_out((h, w) if c == 1 else (h, w, c))
 	check(load().ogd_png_decode_u8(ctypes.cast(ctypes.c_char_p(data), c_void_p), len(data), _ptr(out), w * c))
 	return out
 

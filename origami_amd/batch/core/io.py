@@ -290,6 +290,15 @@ class Reader(_PageFiles):
 	def flow(self):
 		return zipfile.ZipFile(self.path(Artifact.FLOW), "r")
 
+	@property
+	def flow_samples(self):
+		"""(samples_h, samples_v) of flow.zip, read once (ref: origami/batch/detect/dewarp.py:72-74)."""
+		def load():
+			from ...dewarp import Samples
+			with self.flow as zf:
+				return Samples.open(zf, "h"), Samples.open(zf, "v")
+		return self._once("flow_samples", load)
+
 
 class Input:
 	"""Declaration of what a stage reads; the processor turns it into a Reader per page."""

@@ -18,6 +18,7 @@ import re
 import sys
 import time
 import traceback
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import click
@@ -121,6 +122,7 @@ class Processor:
 		self._devices = get("devices") or ""
 		self._rank = 0
 		self._device = None
+		self._prefetcher = None
 		if get("profile") or get("track_changes") or get("debug_write"):
 			logging.warning("--profile, --track-changes and --debug-write are not supported by this build.")
 
@@ -145,6 +147,15 @@ class Processor:
 
 	def should_process(self, page_path):
 		return True
+
+	def prefetch(self, page_path, **kwargs):
+		"""Called with the NEXT page's readers / writers on a side thread while process() works on the current page:
+		a stage starts here whatever its process() would wait for first — reading and inflating the page's
+		archives, decoding the scan into pinned memory — so that the host work of page k + 1 overlaps the device
+		work of page k.  Whatever it loads must land in the readers' own caches (Reader._once): process() then finds
+		it there.  Errors are dropped; process() meets them again in context.  Default: nothing.
+		The reference gets this overlap from its process pool alone (ref: origami/batch/core/processor.py:476-493);
+		a GPU worker has a device to keep busy as well."""
 
 	def is_image(self, path):
 		if path.suffix.lower() in IMAGE_SUFFIXES:
@@ -212,9 +223,29 @@ class Processor:
 		groups = [[item] for item in chunk] if isinstance(self._mutex, FileMutex) else [chunk]
 		for group in groups:
 			with self._mutex.lock(actor, [str(page) for _, page, _ in group]) as locked:
-				for index, page, files in group:
+				ahead = None
+				for k, (index, page, files) in enumerate(group):
+					mine, ahead = ahead, None
+					if locked and k + 1 < len(group):
+						ahead = self._start_prefetch(group[k + 1][1], group[k + 1][2])
+					if mine is not None:
+						mine.result()  # never raises (_prefetch_quietly)
 					self._run_page(page, files, locked)
 					yield index, page
+
+	def _start_prefetch(self, page, files):
+		if type(self).prefetch is Processor.prefetch:
+			return None
+		if self._prefetcher is None:
+			self._prefetcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prefetch")
+		return self._prefetcher.submit(self._prefetch_quietly, page, files)
+
+	def _prefetch_quietly(self, page, files):
+		try:
+			if all(f.is_ready() for f in files.values()):
+				self.prefetch(page, **files)
+		except Exception:
+			logging.debug("prefetch of %s failed:\n%s" % (page, traceback.format_exc()))
 
 	# ---- queue ---------------------------------------------------------------------------------------
 

@@ -16,7 +16,7 @@ import click
 import numpy as np
 
 from ... import _shim
-from ...dewarp import Grid, Samples
+from ...dewarp import Grid
 from ...geometry import holes_inside, parse_wkt_many, ring_table, rings_valid_table, to_wkt
 from ...repair import RepairError
 from ..core.io import Artifact, Input, Output, Stage
@@ -115,15 +115,20 @@ class DewarpProcessor(Processor):
 			("output", Output(Artifact.DEWARPING_TRANSFORM, Artifact.CONTOURS, stage=Stage.DEWARPED)),
 		]
 
+	def prefetch(self, page_path, warped, output):
+		"""Host-side inputs of the next page while this one is on the device: the contour archive read, inflated and
+		its regions parsed, the flow samples, the page's header (its size is all this stage asks of it)."""
+		if warped.regions.by_path:
+			warped.page.size(False)
+			warped.flow_samples
+
 	def process(self, page_path: Path, warped, output):
 		blocks = warped.regions.by_path
 		if not blocks:
 			return
 
 		page = warped.page
-		with warped.flow as zf:
-			samples_h = Samples.open(zf, "h")
-			samples_v = Samples.open(zf, "v")
+		samples_h, samples_v = warped.flow_samples
 
 		grid = Grid.create(page, samples_h, samples_v, grid_res=self._options["grid_cell_size"])
 

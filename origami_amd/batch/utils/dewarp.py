@@ -26,6 +26,11 @@ class DewarpProcessor(Processor):
 		source = io.Input(io.Artifact.DEWARPING_TRANSFORM, stage=io.Stage.DEWARPED)
 		return [("dewarped", source), ("output", io.Output(io.Annotation("dewarped")))]
 
+	def prefetch(self, page_path, dewarped, output):
+		"""The next page's grid (dewarp.zip) and scan — file bytes of a JPEG the device decodes, decoded pixels in pinned
+		memory for everything else — while this page is on the device."""
+		dewarped.page.prefetch()
+
 	def process(self, page_path, dewarped, output):
 		# the reference saves the PIL image `dewarped.page.dewarped`; the same file comes encoded from the device
 		output.annotation(dewarped.page.dewarped_jpeg())

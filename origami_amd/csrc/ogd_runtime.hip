@@ -231,4 +231,133 @@ int ogd_stream_sync(void* stream) {
   return OGD_OK;
 }
 
+int ogd_memcpy2d_h2d(void* dptr, size_t dpitch, const void* hptr, size_t hpitch, size_t width, size_t rows,
+                     void* stream) {
+  OGD_REQUIRE(dptr && hptr, "null pointer");
+  OGD_REQUIRE(dpitch >= width && hpitch >= width, "pitch shorter than a row");
+  OGD_TRY(ensure_device());
+  if (dpitch == width && hpitch == width)
+    OGD_HIP(hipMemcpyAsync(dptr, hptr, width * rows, hipMemcpyHostToDevice, as_stream(stream)));
+  else
+    OGD_HIP(hipMemcpy2DAsync(dptr, dpitch, hptr, hpitch, width, rows, hipMemcpyHostToDevice, as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_memcpy2d_d2h(void* hptr, size_t hpitch, const void* dptr, size_t dpitch, size_t width, size_t rows,
+                     void* stream) {
+  OGD_REQUIRE(dptr && hptr, "null pointer");
+  OGD_REQUIRE(dpitch >= width && hpitch >= width, "pitch shorter than a row");
+  OGD_TRY(ensure_device());
+  if (dpitch == width && hpitch == width)
+    OGD_HIP(hipMemcpyAsync(hptr, dptr, width * rows, hipMemcpyDeviceToHost, as_stream(stream)));
+  else
+    OGD_HIP(hipMemcpy2DAsync(hptr, hpitch, dptr, dpitch, width, rows, hipMemcpyDeviceToHost, as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  OGD_TRY(ensure_device());
+  size_t f = 0, t = 0;
+  OGD_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return OGD_OK;
+}
+
+// ---- pinned host memory, streams, events: what a caller needs to overlap copies with kernels -----------
+
+int ogd_host_alloc(void** hptr, size_t bytes) {
+  OGD_REQUIRE(hptr != nullptr, "hptr is NULL");
+  OGD_TRY(ensure_device());
+  *hptr = nullptr;
+  hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(OGD_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return OGD_OK;
+}
+
+int ogd_host_free(void* hptr) {
+  if (!hptr) return OGD_OK;
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipHostFree(hptr));
+  return OGD_OK;
+}
+
+int ogd_stream_create(void** stream) {
+  OGD_REQUIRE(stream != nullptr, "stream is NULL");
+  OGD_TRY(ensure_device());
+  hipStream_t s = nullptr;
+  // non-blocking: the host-buffer entry points work on the null stream and must not serialise a pipeline
+  OGD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return OGD_OK;
+}
+
+int ogd_stream_destroy(void* stream) {
+  if (!stream) return OGD_OK;
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipStreamDestroy(as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_stream_wait_event(void* stream, void* event) {
+  OGD_REQUIRE(event != nullptr, "event is NULL");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+  return OGD_OK;
+}
+
+int ogd_event_create(void** event, int timing) {
+  OGD_REQUIRE(event != nullptr, "event is NULL");
+  OGD_TRY(ensure_device());
+  hipEvent_t e = nullptr;
+  OGD_HIP(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming));
+  *event = e;
+  return OGD_OK;
+}
+
+int ogd_event_destroy(void* event) {
+  if (!event) return OGD_OK;
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+  return OGD_OK;
+}
+
+int ogd_event_record(void* event, void* stream) {
+  OGD_REQUIRE(event != nullptr, "event is NULL");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+  return OGD_OK;
+}
+
+int ogd_event_sync(void* event) {
+  OGD_REQUIRE(event != nullptr, "event is NULL");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+  return OGD_OK;
+}
+
+int ogd_event_query(void* event, int* done) {
+  OGD_REQUIRE(event != nullptr && done != nullptr, "null pointer");
+  OGD_TRY(ensure_device());
+  hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(event));
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    *done = 0;
+    return OGD_OK;
+  }
+  OGD_HIP(e);
+  *done = 1;
+  return OGD_OK;
+}
+
+int ogd_event_elapsed_ms(void* start, void* stop, float* ms) {
+  OGD_REQUIRE(start && stop && ms, "null pointer");
+  OGD_TRY(ensure_device());
+  OGD_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return OGD_OK;
+}
+
 }  // extern "C"

@@ -47,12 +47,31 @@ class Page:
 		self._device_page = None
 		self._grid = dewarping_transform
 		self._dewarper = None
+		self._file_bytes = None
+
+	def _read_file(self):
+		if self._file_bytes is None:
+			self._file_bytes = Path(self._opened.filename).read_bytes()
+		return self._file_bytes
+
+	def prefetch(self):
+		"""What a stage that will look at this page's pixels can start before it gets to the page (the batch runtime
+		calls it for page k + 1 on a side thread while page k is on the device): a JPEG scan the device decodes is
+		only read from disk — decode, dewarp and encode happen in one device call later —, any other file is decoded
+		now (PNG: libogdewarp's inflate, else PIL), into pinned memory that goes up at the link's rate."""
+		if self._warped is not None:
+			return
+		if self._on_device_format():
+			self._read_file()
+		else:
+			self.warped
 
 	@property
 	def warped(self):
 		if self._warped is None:
 			self._warped = self._decode_on_device() or self._decode_png() or self._opened.convert("L")
 			self._opened = None
+			self._file_bytes = None
 		return self._warped
 
 	def _decode_on_device(self):
@@ -61,7 +80,7 @@ class Page:
 		returns None and goes through PIL as in the reference (ref: page.py:82-84)."""
 		if not self._on_device_format():
 			return None
-		data = Path(self._opened.filename).read_bytes()
+		data = self._read_file()
 		pixels = _shim.jpeg_decode_gray(data)
 		if pixels is None:
 			return None
@@ -77,7 +96,7 @@ class Page:
 			return None
 		try:
 			pixels = _shim.png_decode(Path(self._opened.filename).read_bytes())
-		except _shim.OgdError:
+		except (_shim.OgdError, MemoryError):  # MemoryError: a header that claims 2^30 x 2^30 pixels
 			return None
 		im = PIL.Image.fromarray(pixels)
 		if im.mode != "L":
@@ -96,7 +115,7 @@ class Page:
 		if self._grid is None:
 			return None
 		if self._warped is None and self._on_device_format():
-			data = Path(self._opened.filename).read_bytes()
+			data = self._read_file()
 			out = _shim.jpeg_dewarp_jpeg_gray(data, self._grid.points("sample"), self._grid.resolution, quality)
 			if out is not None:
 				return out
@@ -131,7 +150,7 @@ class Page:
 		"""The warped page resident in device memory; line images are cut from it (block.py:255)."""
 		if self._device_page is None:
 			if self._warped is None and self._on_device_format():  # an undecoded JPEG scan never visits the host
-				self._device_page = _shim.DevicePage.from_jpeg(Path(self._opened.filename).read_bytes())
+				self._device_page = _shim.DevicePage.from_jpeg(self._read_file())
 			if self._device_page is None:
 				warped = self.warped
 				self._device_page = _shim.DevicePage(self._pixels if self._pixels is not None else np.asarray(warped))
