@@ -227,32 +227,6 @@ def cpu_baseline(wl, threads, budget_s=12.0):
 			n, spent, t_pix, threads, len(wl["polys"][0]["rings"]), t_pts))
 
 
-def bind_to_gpu_numa_node(torch, local_rank):
-	"""Pin this rank's threads (and with them the pinned host ring it is about to allocate: first touch) to the
-	NUMA node its GPU hangs off, so that eight ranks do not stage through one socket's DRAM.  Best effort: any
-	failure leaves the affinity alone.  Returns the node number or None."""
-	try:
-		hip = ctypes.CDLL("libamdhip64.so")
-		buf = ctypes.create_string_buffer(64)
-		if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) != 0:
-			return None
-		bus = buf.value.decode().lower()
-		node = int(Path("/sys/bus/pci/devices/%s/numa_node" % bus).read_text())
-		if node < 0:
-			return None
-		cpus = set()
-		for part in Path("/sys/devices/system/node/node%d/cpulist" % node).read_text().strip().split(","):
-			a, _, b = part.partition("-")
-			cpus.update(range(int(a), int(b or a) + 1))
-		cpus &= os.sched_getaffinity(0)
-		if not cpus:
-			return None
-		os.sched_setaffinity(0, cpus)
-		return node
-	except Exception:
-		return None
-
-
 def pipeline_leg(torch, wl, n_jobs, barrier, streams, slots=3):
 	"""BASELINE.json configs[2] per GPU through the PRODUCT's pipeline class
 	(origami_amd/pipeline.py:PagePipeline): `n_jobs` page jobs drawn by cycling the batch's pages from a PINNED HOST
@@ -389,7 +363,10 @@ def main():
 
 	if not torch.cuda.is_available():
 		raise SystemExit("bench.py needs a GPU (no CPU fallback exists on the product path)")
-	numa_node = bind_to_gpu_numa_node(torch, local_rank) if world > 1 else None
+	# ranks of an N > 1 run stage their pinned rings through the DRAM of their own GPU's socket (origami_amd/numa.py:
+	# the helper the stage workers use)
+	from origami_amd import numa
+	numa_node = numa.bind_to_gpu_numa_node(local_rank) if world > 1 else None
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
 	_shim.init(local_rank)

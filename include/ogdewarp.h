@@ -48,6 +48,10 @@ int ogd_version(void);
 int ogd_device_count(int* count);
 /* Bind the calling thread to `device` (-1: OGD_DEVICE env, else 0) and create its context. */
 int ogd_init(int device);
+/* PCI address of a GPU ("0000:c1:00.0"; does not create a context): a worker finds the NUMA node its GPU hangs
+ * off under /sys/bus/pci/devices/<address>/numa_node and pins itself — and with it the pinned page buffers it is
+ * about to allocate — to that node's cores (origami_amd/numa.py).  out: at least 16 bytes. */
+int ogd_device_pci_bus_id(int device, char* out, int cap);
 /* The host-buffer entry points keep the device blocks they used in a per-thread cache; this frees the
  * calling thread's idle ones (bytes freed are returned through freed_bytes if it is not NULL). */
 int ogd_trim(size_t* freed_bytes);

@@ -37,6 +37,7 @@ SIGNATURES = {
 	"ogd_version": (c_int, []),
 	"ogd_device_count": (c_int, [POINTER(c_int)]),
 	"ogd_init": (c_int, [c_int]),
+	"ogd_device_pci_bus_id": (c_int, [c_int, c_char_p, c_int]),
 	"ogd_trim": (c_int, [POINTER(c_size_t)]),
 	"ogd_dev_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
 	"ogd_dev_free": (c_int, [c_void_p]),
@@ -186,6 +187,14 @@ def device_count():
 
 def init(device=-1):
 	check(load().ogd_init(int(device)))
+
+
+def device_pci_bus_id(device):
+	"""'0000:c1:00.0' of GPU `device`, or None (no such device, no driver)."""
+	buf = ctypes.create_string_buffer(64)
+	if load().ogd_device_pci_bus_id(int(device), buf, 64) != 0:
+		return None
+	return buf.value.decode("ascii", "replace").lower() or None
 
 
 def _ptr(a):

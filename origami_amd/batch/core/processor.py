@@ -38,9 +38,14 @@ def _worker_main(processor_cls, options, data_path, rank, device, task_q, done_q
 	"""Body of one spawned worker: bind to its GPU, then pull chunks of page paths until the queue
 	hands out None."""
 	try:
+		numa_node = None
 		if device is not None:
 			os.environ["OGD_DEVICE"] = str(device)
+			# run on the cores next to the GPU before anything allocates pinned page buffers (first touch)
+			from ... import numa
+			numa_node = numa.bind_to_gpu_numa_node(device)
 		processor = processor_cls(options)
+		processor._numa_node = numa_node
 		processor._rank = rank
 		processor._device = device
 		processor._mutex = processor._make_mutex(data_path)
@@ -87,7 +92,10 @@ _CLI = (
 	("--plain", dict(is_flag=True, default=False, help="One line per finished page, for pipes.")),
 	("--debug-write", dict(is_flag=True, default=False, help="(accepted for compatibility; not supported)")),
 	("--track-changes", dict(type=str, default="", help="(accepted for compatibility; not supported)")),
-	("--gpus", dict(type=int, default=0, help="Worker processes, one per GPU (0: work in this process).")),
+	("--gpus", dict(type=int, default=0, help="GPUs to spread the pages over with spawned workers (0: work in this process).")),
+	("--workers-per-gpu", dict(
+		type=int, default=0,
+		help="Worker processes per GPU (0: as many as half the usable cores allow, at most 8; the stages are host-bound).")),
 	("--devices", dict(type=str, default="", help="Comma separated GPU indices to use (default: all visible).")),
 )
 
@@ -119,7 +127,9 @@ class Processor:
 			raise ValueError(self._lock_level)
 
 		self._gpus = get("gpus", 0) or 0
+		self._workers_per_gpu = get("workers_per_gpu", 0) or 0
 		self._devices = get("devices") or ""
+		self._numa_node = None
 		self._rank = 0
 		self._device = None
 		self._prefetcher = None
@@ -311,7 +321,8 @@ class Processor:
 		return DatabaseMutex(database, timeout=self._lock_timeout)
 
 	def worker_devices(self, n_workers):
-		"""GPU index of every worker: worker r -> devices[r % len(devices)]."""
+		"""GPU index of every worker: worker r -> devices[r % len(devices)], so with K workers per GPU the workers of a
+		GPU are r, r + n, r + 2n ... ([0..7, 0..7] for 16 workers over 8 GPUs)."""
 		if self._devices:
 			devices = [int(d) for d in str(self._devices).split(",") if d.strip() != ""]
 		else:
@@ -319,13 +330,23 @@ class Processor:
 			devices = list(range(max(1, _shim.device_count())))
 		return [devices[r % len(devices)] for r in range(n_workers)]
 
+	def gpu_worker_count(self):
+		"""--gpus N x --workers-per-gpu K spawned workers (K = 0: numa.auto_workers_per_gpu)."""
+		if self._gpus <= 0:
+			return 0
+		per_gpu = self._workers_per_gpu
+		if per_gpu <= 0:
+			from ... import numa
+			per_gpu = numa.auto_workers_per_gpu(self._gpus)
+		return self._gpus * per_gpu
+
 	def _progress(self, i, p, total):
 		if self._print_paths:
 			nd = len(str(total))
 			print(f"[{str(i + 1).rjust(nd)} / {total}] {p}", flush=True)
 
 	def _process_queue(self, queued, data_path):
-		n_workers = self._gpus if self._gpus > 0 else self._processes
+		n_workers = self.gpu_worker_count() if self._gpus > 0 else self._processes
 		if n_workers <= 1:
 			if self._gpus == 1:
 				self._device = self.worker_devices(1)[0]

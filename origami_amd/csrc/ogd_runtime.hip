@@ -188,6 +188,17 @@ int ogd_device_count(int* count) {
 
 int ogd_init(int device) { return bind_device(device); }
 
+int ogd_device_pci_bus_id(int device, char* out, int cap) {
+  OGD_REQUIRE(out != nullptr && cap >= 16, "out must hold at least 16 bytes");
+  out[0] = 0;
+  hipError_t e = hipDeviceGetPCIBusId(out, cap, device);  // no context is created
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(OGD_ERR_NODEVICE, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+  }
+  return OGD_OK;
+}
+
 int ogd_trim(size_t* freed_bytes) {
   const size_t n = pool_trim();
   if (freed_bytes) *freed_bytes = n;

@@ -130,7 +130,7 @@ def test_two_gpu_workers_share_one_queue(tmp_path, lock, monkeypatch):
 	rdv = tmp_path.parent / (tmp_path.name + ".rdv")
 	rdv.mkdir()
 	monkeypatch.setenv("FAKE_STAGE_RENDEZVOUS", "%s:2" % rdv)  # no worker finishes before both have started
-	proc = FakeDewarpProcessor(options(gpus=2, devices="0,1", lock_strategy=lock))
+	proc = FakeDewarpProcessor(options(gpus=2, workers_per_gpu=1, devices="0,1", lock_strategy=lock))
 	assert proc.worker_devices(4) == [0, 1, 0, 1]
 	proc.traverse(tmp_path)
 	seen = {}
@@ -153,9 +153,83 @@ def test_a_worker_killed_by_a_signal_fails_the_stage_and_frees_its_locks(tmp_pat
 	must be gone so that a re-run can take its pages at once."""
 	make_pages(tmp_path, 2, prefix="kill")
 	make_pages(tmp_path, 4, prefix="page")
-	proc = FakeDewarpProcessor(options(gpus=2, devices="0,1", lock_strategy="DB", alive=30))
+	proc = FakeDewarpProcessor(options(gpus=2, workers_per_gpu=1, devices="0,1", lock_strategy="DB", alive=30))
 	with pytest.raises(SystemExit) as e:
 		proc.traverse(tmp_path)
 	assert e.value.code == 1
 	assert not (tmp_path / "kill0000.out" / "dewarp.zip").exists()
 	assert DatabaseMutex(tmp_path / "origami.lock.db", timeout=5).held() == []
+
+
+def test_workers_per_gpu_are_dealt_round_robin_over_the_gpus():
+	"""--gpus 8 --workers-per-gpu 2: sixteen workers, worker r on GPU r % 8 ([0..7, 0..7]); without the option the
+	count comes from the usable cores (half of them, at most 8 per GPU, at least 1)."""
+	from origami_amd import numa
+	proc = FakeDewarpProcessor(options(gpus=8, workers_per_gpu=2, devices="0,1,2,3,4,5,6,7"))
+	assert proc.gpu_worker_count() == 16
+	assert proc.worker_devices(proc.gpu_worker_count()) == list(range(8)) * 2
+	assert FakeDewarpProcessor(options(gpus=0)).gpu_worker_count() == 0
+	assert numa.auto_workers_per_gpu(8, cpus=256) == 8  # capped
+	assert numa.auto_workers_per_gpu(8, cpus=96) == 6
+	assert numa.auto_workers_per_gpu(1, cpus=8) == 4
+	assert numa.auto_workers_per_gpu(8, cpus=4) == 1
+	auto = FakeDewarpProcessor(options(gpus=2, devices="0,1"))
+	assert auto.gpu_worker_count() == 2 * numa.auto_workers_per_gpu(2)
+
+
+def _fake_sysfs(root):
+	"""Two NUMA nodes of 8 cores; GPUs c1 on node 0, e1 on node 1, a device whose node is unknown (-1)."""
+	for node, cpulist in ((0, "0-3,8-11"), (1, "4-7,12-15")):
+		d = root / "devices" / "system" / "node" / ("node%d" % node)
+		d.mkdir(parents=True)
+		(d / "cpulist").write_text(cpulist + "\n")
+	for bus, node in (("0000:c1:00.0", 0), ("0000:e1:00.0", 1), ("0000:05:00.0", -1)):
+		d = root / "bus" / "pci" / "devices" / bus
+		d.mkdir(parents=True)
+		(d / "numa_node").write_text("%d\n" % node)
+
+
+def test_numa_helper_reads_a_sysfs_tree(tmp_path):
+	from origami_amd import numa
+	_fake_sysfs(tmp_path)
+	assert numa.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+	assert numa.node_of_pci_device("0000:E1:00.0", tmp_path) == 1
+	assert numa.node_of_pci_device("0000:05:00.0", tmp_path) is None
+	assert numa.node_of_pci_device("0000:99:00.0", tmp_path) is None
+	assert numa.cpus_of_node(1, tmp_path) == {4, 5, 6, 7, 12, 13, 14, 15}
+	bound = []
+	every = set(range(16))
+	node = numa.bind_to_gpu_numa_node(
+		1, sysfs=tmp_path, bus_id="0000:e1:00.0", setaffinity=bound.append, getaffinity=lambda: every)
+	assert node == 1 and bound == [{4, 5, 6, 7, 12, 13, 14, 15}]
+	# a container that only grants some of the node's cores: the intersection
+	bound.clear()
+	assert numa.bind_to_gpu_numa_node(
+		0, sysfs=tmp_path, bus_id="0000:c1:00.0", setaffinity=bound.append, getaffinity=lambda: {2, 3, 4}) == 0
+	assert bound == [{2, 3}]
+
+
+def test_a_worker_that_cannot_bind_still_runs(tmp_path):
+	"""No NUMA information, none of the node's cores granted, no such GPU, a failing sched_setaffinity: the helper
+	answers None and leaves the affinity alone; the spawned workers of a stage (which call it with device indices
+	that do not exist in this container) do their pages all the same."""
+	from origami_amd import numa
+	sysfs = tmp_path / "sys"
+	_fake_sysfs(sysfs)
+	bound = []
+	every = set(range(16))
+	assert numa.bind_to_gpu_numa_node(0, sysfs=sysfs, bus_id="0000:05:00.0", setaffinity=bound.append, getaffinity=lambda: every) is None
+	assert numa.bind_to_gpu_numa_node(0, sysfs=sysfs, bus_id="0000:c1:00.0", setaffinity=bound.append, getaffinity=lambda: {4, 5}) is None
+	assert numa.bind_to_gpu_numa_node(0, sysfs=tmp_path / "none", bus_id="0000:c1:00.0", setaffinity=bound.append, getaffinity=lambda: every) is None
+
+	def refuse(cpus):
+		raise OSError("not permitted")
+	assert numa.bind_to_gpu_numa_node(0, sysfs=sysfs, bus_id="0000:c1:00.0", setaffinity=refuse, getaffinity=lambda: every) is None
+	assert bound == []
+	assert numa.bind_to_gpu_numa_node(5) is None  # no GPU 5 here (no GPU at all in the build container)
+	pages = make_pages(tmp_path, 4)
+	proc = FakeDewarpProcessor(options(gpus=2, workers_per_gpu=2, devices="0,1"))
+	proc.traverse(tmp_path)
+	for p in pages:
+		info = json.loads((find_data_path(p) / "runtime.json").read_text())["fake.dewarp"]
+		assert info["status"] == "COMPLETED" and "numa_node" not in info

@@ -289,7 +289,7 @@ def test_two_spawned_workers_on_one_gpu_equal_the_in_process_run(gpu, tmp_path):
 	shutil.copytree(a, b)
 	res = CliRunner().invoke(dewarp, [str(a), "--lock-strategy", "NONE", "--plain"])
 	assert res.exit_code == 0, res.output
-	res = CliRunner().invoke(dewarp, [str(b), "--gpus", "2", "--plain"])
+	res = CliRunner().invoke(dewarp, [str(b), "--gpus", "2", "--workers-per-gpu", "1", "--plain"])
 	assert res.exit_code == 0, res.output
 	for k in range(4):
 		oa, ob = a / ("page%04d.out" % k), b / ("page%04d.out" % k)
