@@ -115,22 +115,27 @@ class DewarpProcessor(Processor):
 			("output", Output(Artifact.DEWARPING_TRANSFORM, Artifact.CONTOURS, stage=Stage.DEWARPED)),
 		]
 
+	def _grid(self, warped):
+		"""The page's node grid (ref: dewarp.py:75-76), built once per Reader."""
+		def create():
+			samples_h, samples_v = warped.flow_samples
+			return Grid.create(warped.page, samples_h, samples_v, grid_res=self._options["grid_cell_size"])
+		return warped._once("created_grid", create)
+
 	def prefetch(self, page_path, warped, output):
-		"""Host-side inputs of the next page while this one is on the device: the contour archive read, inflated and
-		its regions parsed, the flow samples, the page's header (its size is all this stage asks of it)."""
+		"""The next page's half of the work that depends on nothing but its own inputs, while this page's contours are
+		warped and written: the contour archive read, inflated and its regions parsed, the flow samples, the page's
+		header (its size is all this stage asks of it), the two angle fields and the march of the node grid (~12 of a
+		page's ~24 ms; the library's host code and its launches release the GIL)."""
 		if warped.regions.by_path:
-			warped.page.size(False)
-			warped.flow_samples
+			self._grid(warped)
 
 	def process(self, page_path: Path, warped, output):
 		blocks = warped.regions.by_path
 		if not blocks:
 			return
 
-		page = warped.page
-		samples_h, samples_v = warped.flow_samples
-
-		grid = Grid.create(page, samples_h, samples_v, grid_res=self._options["grid_cell_size"])
+		grid = self._grid(warped)
 
 		# dewarp.zip is 600 KB of float32 that deflate chews on for 14 ms (zlib releases the GIL): it is written by
 		# a second thread while this one builds the transformer and warps the contours (most of that time is spent

@@ -47,7 +47,7 @@ def main():
 		def run(overwrite, workers=workers):
 			args = [str(root), "--lock-strategy", "NONE", "--plain"] + (["--overwrite"] if overwrite else [])
 			if workers:
-				args += ["--gpus", str(workers)]
+				args += ["--gpus", "1", "--workers-per-gpu", str(workers)]
 			t = time.perf_counter()
 			res = CliRunner().invoke(dewarp, args)
 			assert res.exit_code == 0, res.output
@@ -68,7 +68,7 @@ def main():
 		from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
 
 		def run_image_stage():
-			args = [str(root), "--lock-strategy", "NONE", "--plain", "--overwrite"] + (["--gpus", str(workers)] if workers else [])
+			args = [str(root), "--lock-strategy", "NONE", "--plain", "--overwrite"] + (["--gpus", "1", "--workers-per-gpu", str(workers)] if workers else [])
 			t = time.perf_counter()
 			res = CliRunner().invoke(dewarp_image_stage, args)
 			assert res.exit_code == 0, res.output
