@@ -55,6 +55,9 @@ int ogd_device_pci_bus_id(int device, char* out, int cap);
 /* The host-buffer entry points keep the device blocks they used in a per-thread cache; this frees the
  * calling thread's idle ones (bytes freed are returned through freed_bytes if it is not NULL). */
 int ogd_trim(size_t* freed_bytes);
+/* Blocks of the calling thread's cache that are in use right now; 0 between calls (a block still counted after an
+ * entry point returned will never be handed out again: what the leak tests watch). */
+int ogd_pool_busy(int* blocks);
 int ogd_dev_alloc(void** dptr, size_t bytes);
 int ogd_dev_free(void* dptr);
 int ogd_memcpy_h2d(void* dptr, const void* hptr, size_t bytes, void* stream);

@@ -39,6 +39,7 @@ SIGNATURES = {
 	"ogd_init": (c_int, [c_int]),
 	"ogd_device_pci_bus_id": (c_int, [c_int, c_char_p, c_int]),
 	"ogd_trim": (c_int, [POINTER(c_size_t)]),
+	"ogd_pool_busy": (c_int, [POINTER(c_int)]),
 	"ogd_dev_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
 	"ogd_dev_free": (c_int, [c_void_p]),
 	"ogd_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

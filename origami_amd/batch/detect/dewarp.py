@@ -153,8 +153,19 @@ class DewarpProcessor(Processor):
 			with output.contours(copy_meta_from=warped) as zf:
 				for name, data in dewarped_contours(warped, grid.transformer, min_areas=min_areas):
 					zf.writestr(name, data)
-		finally:
-			saving.result()
+		except BaseException:
+			# The reference writes the contours first and never writes the grid after a contour failure (ref:
+			# dewarp.py:84-90): take the grid back, and let the saver's own failure, if any, not mask this one.
+			try:
+				saving.result()
+			except Exception:
+				logging.exception("writing %s failed as well." % output.path(Artifact.DEWARPING_TRANSFORM))
+			try:
+				output.path(Artifact.DEWARPING_TRANSFORM).unlink()
+			except OSError:
+				pass
+			raise
+		saving.result()
 
 
 @click.command()

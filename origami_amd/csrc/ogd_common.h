@@ -42,6 +42,8 @@ int ensure_device();
 // ogd_trim() gives the calling thread's idle blocks back.
 void* pool_take(size_t bytes);  // nullptr on failure (error already set)
 void pool_give(void* p);
+// blocks of the calling thread's cache that are handed out right now (for leak tests: ogd_pool_busy)
+int pool_busy_count();
 // A pinned host buffer of the calling thread for packing several small uploads into one asynchronous copy (a
 // synchronous copy from pageable memory costs ~60 us whatever its size).  Valid until the thread's next call; the
 // caller synchronises before it returns.  nullptr if pinned memory cannot be had: copy from where the data lies.
@@ -54,6 +56,7 @@ struct DevBuf {
     if (p) pool_give(p);
   }
   int alloc(size_t bytes) {
+    if (p) pool_give(p);  // a second alloc on the same buffer must not strand the first block as busy for ever
     p = pool_take(bytes ? bytes : 16);
     return p ? OGD_OK : OGD_ERR_NOMEM;
   }

@@ -39,8 +39,12 @@ inline uint32_t reverse_bits(uint32_t code, int len) {  // len <= 15
 }
 
 // Canonical Huffman decoding table for `n` symbols of code lengths lens[] (0 = unused).  payload[s] holds bits 8..31
-// of symbol s's entry.  Returns false for an over-subscribed code or a table that would not fit.
-inline bool build_table(const uint8_t* lens, int n, const uint32_t* payload, int table_bits, uint32_t* table, int cap) {
+// of symbol s's entry.  Returns false for an over-subscribed code, a table that would not fit, and — as zlib's
+// inflate_table does ("invalid code lengths set", "invalid literal/lengths set", "invalid distances set") — for an
+// INCOMPLETE set, unless it is a single code of length 1 (allowed for literal / length and distance codes, never for the
+// code-length code: may_be_single) or has no codes at all (a block without matches has no distance codes).
+inline bool build_table(const uint8_t* lens, int n, const uint32_t* payload, int table_bits, uint32_t* table, int cap,
+                        bool may_be_single = true) {
   int count[16] = {0};
   for (int s = 0; s < n; ++s) ++count[lens[s]];
   count[0] = 0;
@@ -52,6 +56,12 @@ inline bool build_table(const uint8_t* lens, int n, const uint32_t* payload, int
     if (left < 0) return false;  // over-subscribed
     code = (code + (uint32_t)count[len - 1]) << 1;
     next[len] = code;
+  }
+  if (left > 0) {  // incomplete
+    int used_codes = 0, max_len = 0;
+    for (int len = 1; len <= 15; ++len)
+      if (count[len]) used_codes += count[len], max_len = len;
+    if (used_codes != 0 && !(may_be_single && max_len == 1)) return false;
   }
   const int primary = 1 << table_bits;
   for (int i = 0; i < primary; ++i) table[i] = 0;  // length 0: an unused code (incomplete sets), BAD_DATA if met
@@ -347,7 +357,7 @@ inline int inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out0, int64_t c
       if (r.past_end()) return TRUNCATED;
       uint32_t ppay[19], ptab[1 << PRE_BITS];
       for (uint32_t s = 0; s < 19; ++s) ppay[s] = s << 8;
-      if (!build_table(plens, 19, ppay, PRE_BITS, ptab, 1 << PRE_BITS)) return BAD_DATA;
+      if (!build_table(plens, 19, ppay, PRE_BITS, ptab, 1 << PRE_BITS, false)) return BAD_DATA;
       int i = 0;
       while (i < nlit + ndist) {
         r.refill_safe();

@@ -1249,7 +1249,8 @@ static int parse_and_decode(const uint8_t* file, size_t n, int H0, int W0, ptrdi
     OGD_TRY(ensure_device());
     uint8_t* target = d_img;
     if (target == nullptr) {
-      OGD_TRY(dimg->alloc((size_t)info.H * info.W));
+      // the careful pass after a trusting one finds the same H x W in the same headers: keep the block
+      if (dimg->p == nullptr) OGD_TRY(dimg->alloc((size_t)info.H * info.W));
       target = dimg->as<uint8_t>();
       stride = info.W;
     }

@@ -39,6 +39,10 @@ int read_header(const uint8_t* file, int64_t n, PngHeader& h) {
   OGD_REQUIRE(compression == 0 && filter == 0, "PNG: unknown compression / filter method");
   if (depth != 8 || (colour != 0 && colour != 2) || interlace != 0)
     return fail(OGD_ERR_UNSUPPORTED, "PNG: bit depth %d, colour type %d, interlace %d is left to PIL", depth, colour, interlace);
+  // PIL warns above MAX_IMAGE_PIXELS (89 478 485) and raises DecompressionBombError above twice that: leave such
+  // headers (a hostile IHDR can claim 2^30 x 2^30) to PIL and its error, before anything is sized from them
+  if ((uint64_t)w * ht > 2ull * 89478485ull)
+    return fail(OGD_ERR_UNSUPPORTED, "PNG: %ux%u pixels is left to PIL (beyond its decompression-bomb limit)", w, ht);
   h.width = (int)w;
   h.height = (int)ht;
   h.channels = colour == 0 ? 1 : 3;
@@ -133,6 +137,7 @@ struct UnfilterShared {
   int64_t out_stride;
   const std::atomic<int64_t>* progress;  // bytes of raw that are final
   const std::atomic<bool>* finished;     // the decoder has returned
+  const uint8_t* zero_row;               // rowbytes zeros: the row above row 0 (allocated before any thread starts)
   std::atomic<int64_t>* done;            // [height] bytes of output row y that are final
   std::atomic<int> bad_row{-1};          // first row with an unknown filter type (-2: the stream ended early)
 };
@@ -145,7 +150,6 @@ constexpr int64_t UNFILTER_CHUNK = 1020;  // whole pixels of 1, 2, 3 or 4 bytes
 
 template <int BPP>
 void unfilter_worker(UnfilterShared& sh, int worker, int nworkers) {
-  std::vector<uint8_t> zero((size_t)sh.rowbytes, 0);
   int64_t ready = 0;
   for (int y = worker; y < sh.height; y += nworkers) {
     if (sh.bad_row.load(std::memory_order_relaxed) != -1) return;
@@ -168,7 +172,7 @@ void unfilter_worker(UnfilterShared& sh, int worker, int nworkers) {
     const int type = f[0];
     ++f;
     uint8_t* o = sh.out + (int64_t)y * sh.out_stride;
-    const uint8_t* prev = y ? sh.out + (int64_t)(y - 1) * sh.out_stride : zero.data();
+    const uint8_t* prev = y ? sh.out + (int64_t)(y - 1) * sh.out_stride : sh.zero_row;
     if (type > 4) {
       sh.bad_row.store(y);
       // rows below wait for this one: let them through, the result is discarded anyway
@@ -219,7 +223,7 @@ int ogd_png_info(const uint8_t* file, int64_t n, int* width, int* height, int* c
   return OGD_OK;
 }
 
-int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_stride) {
+static int png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_stride) {
   PngHeader h;
   OGD_TRY(read_header(file, n, h));
   OGD_REQUIRE(out != nullptr, "null pointer");
@@ -256,8 +260,10 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
   std::unique_ptr<std::atomic<int64_t>[]> done(new (std::nothrow) std::atomic<int64_t>[(size_t)h.height]);
   if (!done) return fail(OGD_ERR_NOMEM, "out of host memory");
   for (int y = 0; y < h.height; ++y) done[y].store(0, std::memory_order_relaxed);
+  const std::vector<uint8_t> zero_row((size_t)rowbytes, 0);
   UnfilterShared sh;
   sh.raw = raw.get();
+  sh.zero_row = zero_row.data();
   sh.height = h.height;
   sh.rowbytes = rowbytes;
   sh.out = out;
@@ -313,6 +319,16 @@ int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_
   if (bad_row >= 0) return fail(OGD_ERR_INVALID, "PNG: unknown filter type %d in row %d", raw[(size_t)bad_row * (rowbytes + 1)], bad_row);
   OGD_REQUIRE(summed == stored, "PNG: image data corrupt (Adler-32 mismatch)");
   return OGD_OK;
+}
+
+int ogd_png_decode_u8(const uint8_t* file, int64_t n, uint8_t* out, int64_t out_stride) {
+  try {  // no C++ exception may cross the C ABI (std::vector growth in the caller's thread)
+    return png_decode_u8(file, n, out, out_stride);
+  } catch (const std::bad_alloc&) {
+    return fail(OGD_ERR_NOMEM, "PNG: out of host memory");
+  } catch (const std::exception& e) {
+    return fail(OGD_ERR_INVALID, "PNG: %s", e.what());
+  }
 }
 
 }  // extern "C"

@@ -127,6 +127,12 @@ void pool_give(void* p) {
   (void)hipFree(p);  // not ours (cannot happen through DevBuf)
 }
 
+int pool_busy_count() {
+  int n = 0;
+  for (auto& b : g_pool.blocks) n += b.p && b.busy;
+  return n;
+}
+
 struct Staging {
   void* p = nullptr;
   size_t bytes = 0;
@@ -202,6 +208,12 @@ int ogd_device_pci_bus_id(int device, char* out, int cap) {
 int ogd_trim(size_t* freed_bytes) {
   const size_t n = pool_trim();
   if (freed_bytes) *freed_bytes = n;
+  return OGD_OK;
+}
+
+int ogd_pool_busy(int* blocks) {
+  OGD_REQUIRE(blocks != nullptr, "blocks is NULL");
+  *blocks = pool_busy_count();
   return OGD_OK;
 }
 

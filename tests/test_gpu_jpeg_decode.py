@@ -161,6 +161,25 @@ def test_end_of_scan_taken_on_trust_and_checked_on_the_device(gpu):
 	assert gpu.jpeg_decode_gray(bytes(body)) is None
 
 
+def test_second_parse_does_not_strand_a_device_block(gpu):
+	"""A file that ends in EOI but holds another marker inside the trusted scan area is parsed twice; the second
+	pass must not take a second H x W block while the first stays marked busy for ever (48 MB per such broadsheet
+	file in a long-running worker).  The calling thread's block cache has no busy block between calls."""
+	import ctypes
+	lib = gpu.load()
+	rng = np.random.default_rng(32)
+	page = synth.text_page(rng, (900, 700))
+	data = ojpeg.save_gray(page) + b"\xff\xd9"
+	want = _pil_decode(data)
+	busy = ctypes.c_int(-1)
+	for _ in range(3):
+		assert np.array_equal(gpu.jpeg_decode_gray(data), want)
+		assert lib.ogd_pool_busy(ctypes.byref(busy)) == 0 and busy.value == 0
+		with gpu.DevicePage.from_jpeg(data) as dp:
+			assert dp is not None
+		assert lib.ogd_pool_busy(ctypes.byref(busy)) == 0 and busy.value == 0
+
+
 def test_large_periodic_stream_is_handed_back_in_bounded_time(gpu):
 	"""A 1-pixel checkerboard at quality 100: every block the same ~700 bits, wrong parses are self-consistent and
 	single lanes would walk the whole 5 MB stream (seconds).  The decoder gives up after its time allowance and the

@@ -426,3 +426,37 @@ def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tm
 	ref = io.BytesIO()
 	want.save(ref, format="JPEG")
 	assert (out / "annotation.dewarped.jpg").read_bytes() == ref.getvalue()
+
+
+def test_a_contour_failure_leaves_no_grid_behind(gpu, tmp_path, monkeypatch):
+	"""The grid is written by a side thread while the contours are warped; if the contours fail, dewarp.zip must not
+	stay behind (the reference writes it after the contours, ref: batch/detect/dewarp.py:84-90), the page is FAILED
+	with the contour error — not the saver's — and a second run with the fault gone completes it.  The second page of
+	the run (its grid was built ahead by the prefetch thread) is unaffected."""
+	import origami_amd.batch.detect.dewarp as stage
+	rng = np.random.default_rng(12)
+	for k in range(2):
+		synth.write_page_dir(
+			tmp_path, "page%04d" % k, rng, size=(500, 650), n_h=100, n_v=130, n_regions=8, n_separators=2,
+			label_size=(250, 325))
+	real = stage.dewarped_contours
+	calls = []
+
+	def failing(warped, transformer, min_areas):
+		calls.append(1)
+		if len(calls) == 1:
+			raise ValueError("synthetic contour failure")
+		return real(warped, transformer, min_areas)
+
+	monkeypatch.setattr(stage, "dewarped_contours", failing)
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	out0, out1 = tmp_path / "page0000.out", tmp_path / "page0001.out"
+	assert not (out0 / "dewarp.zip").exists() and not (out0 / "contours.1.zip").exists()
+	info = json.loads((out0 / "runtime.json").read_text())["origami.batch.detect.dewarp"]
+	assert info["status"] == "FAILED" and "synthetic contour failure" in info["traceback"]
+	assert (out1 / "dewarp.zip").exists() and (out1 / "contours.1.zip").exists()
+	res = CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
+	assert res.exit_code == 0, res.output
+	assert (out0 / "dewarp.zip").exists() and (out0 / "contours.1.zip").exists()
+	assert json.loads((out0 / "runtime.json").read_text())["origami.batch.detect.dewarp"]["status"] == "COMPLETED"
