@@ -153,12 +153,13 @@ int ogd_dewarp_jpeg_gray(const uint8_t* src, int H, int W, ptrdiff_t src_stride,
 
 /* ---- N4: decoding the page image ------------------------------------------------------------------
  * ref: origami/core/page.py:82-84 (`PIL.Image.open(path).convert("L")`).  A baseline JPEG decoder on the device
- * for 8-bit Huffman files without restart markers, one component (grayscale) or three (JFIF YCbCr in one
- * interleaved scan, 4:4:4 / 4:2:2 / 4:2:0): the pixels `convert("L")` gives after PIL / libjpeg-turbo decoded the
+ * for 8-bit Huffman files, with or without restart intervals (DRI / RSTn), one component (grayscale) or three
+ * (JFIF YCbCr in one interleaved scan, 4:4:4 / 4:2:2 / 4:2:0): the pixels `convert("L")` gives after PIL / libjpeg-turbo decoded the
  * file, bit for bit (Huffman decoding in parallel by fixed-point iteration over 512-bit chunks, islow IDCT,
  * libjpeg's fancy chroma upsampling and YCbCr -> RGB tables, PIL's RGB -> L).
  * ogd_jpeg_info: size and component count of any JPEG file; *supported = 1 if this decoder covers it (else
- * ogd_last_error() names the reason and the caller keeps its own decoder — progressive, DRI, CMYK / Adobe ...).
+ * ogd_last_error() names the reason and the caller keeps its own decoder — progressive, arithmetic coding, 12 bit,
+ * CMYK / Adobe, several scans ...).
  * ogd_jpeg_decode_gray: file bytes -> [H][W] uint8 (host, row stride in bytes); OGD_ERR_UNSUPPORTED for a file
  * outside the decoder's domain; OGD_ERR_RUNTIME for a scan this decoder gives up on (too few blocks, restart
  * markers that do not stand where the blocks say, a stream periodic throughout whose chunk states settle too
@@ -380,7 +381,9 @@ int ogd_march_grid(const ogd_tri* inner_h, const ogd_tri* extra_h, double phi0_h
                    const double* bounds, int s, int n_rows, int n_cols, int num_slices,
                    float* grid_h, float* grid_hv);
 /* ogd_march_grid for callers that cannot allocate.  No counterpart in the reference: it exists for callers that
- * may not call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * may not call hipMalloc — tight serving loops, harnesses that forbid allocation.  (It is a synchronous call like
+ * ogd_march_grid — blocking copies of the results to the host on the null stream —, so it cannot itself be
+ * captured into a HIP graph.)
  * Same arguments, same results (it runs the same kernels), but its device buffers — both node grids, the slice
  * ray lengths, the status record — are a fixed ~4 MiB array in the library's device image, held by every GPU the
  * library runs on until the process ends; no hipMalloc / hipFree or other allocating routine is called.

@@ -1,0 +1,125 @@
+"""`Document.rewarp` (ref: origami/batch/detect/compose.py:413-432) through a REAL warped grid on the GPU: every
+outline of a page through `Grid.inverse` in one ogd_grid_sample_bilinear launch, then validity / convex hull / clip
+to the page on the host — against scipy's RegularGridInterpolator over the oracle's dense grid (what the reference
+calls, ref: origami/core/dewarp.py:561-576) and an independent point-membership statement of "outline ∩ page"
+(oracle/rings.py: winding numbers and even-odd crossing counts, no overlay code)."""
+
+import numpy as np
+import pytest
+
+from oracle import dewarp as odw
+from oracle import rings as orings
+from origami_amd import synth
+from origami_amd.batch.detect.compose import Rewarper
+from origami_amd.dewarp import Grid
+from origami_amd.geometry import Geom, convex_hull_ring
+
+pytestmark = pytest.mark.gpu
+
+SIZE = (900, 1200)  # warped page (W, H)
+CELL = 25
+
+
+def _outlines(rng, dewarped_size, n):
+	"""Star-shaped outlines in dewarped pixels: most inside the page, a quarter reaching over one of its edges, a few
+	wholly outside, plus a bow-tie (invalid: its convex hull counts) and a U whose back lies off the page."""
+	Wd, Hd = dewarped_size
+	out = []
+	for k in range(n):
+		m = int(rng.integers(5, 40))
+		ang = np.sort(rng.uniform(0, 2 * np.pi, size=m))
+		rad = rng.uniform(15, 90) * rng.uniform(0.6, 1.0, size=m)
+		kind = k % 8
+		if kind == 5:  # over an edge
+			c = [(0, rng.uniform(0, Hd)), (Wd, rng.uniform(0, Hd)), (rng.uniform(0, Wd), 0), (rng.uniform(0, Wd), Hd)][k // 8 % 4]
+		elif kind == 6 and k % 16 == 6:  # beyond the page and its border nodes
+			c = (-400 - rng.uniform(0, 100), rng.uniform(0, Hd))
+		else:
+			c = (rng.uniform(100, Wd - 100), rng.uniform(100, Hd - 100))
+		out.append(np.stack([c[0] + rad * np.cos(ang), c[1] + rad * np.sin(ang)], axis=1))
+	out.append(np.array([(200, 200), (300, 300), (300, 200), (200, 300)], dtype=np.float64))  # bow-tie
+	out.append(np.array([(-60, 400), (90, 400), (90, 420), (-20, 420), (-20, 500), (90, 500), (90, 520), (-60, 520)], dtype=np.float64))
+	return out
+
+
+def _closed(ring):
+	ring = np.asarray(ring, dtype=np.float64)
+	return ring if np.array_equal(ring[0], ring[-1]) else np.vstack([ring, ring[:1]])
+
+
+def _distance_to_ring(ring, p):
+	a, b = ring[:-1], ring[1:]
+	d = b - a
+	t = np.clip(np.einsum("ij,ij->i", p - a, d) / np.maximum(np.einsum("ij,ij->i", d, d), 1e-300), 0, 1)
+	return float(np.hypot(*(a + t[:, None] * d - p).T).min())
+
+
+def test_rewarp_of_a_page_through_a_real_grid(gpu):
+	rng = np.random.default_rng(41)
+	nodes = synth.Warp(SIZE, 0.035, 0.03, 1, 2).node_grid(CELL)
+	grid = Grid(nodes, CELL)
+	ogrid = odw.Grid(nodes, CELL)
+	dewarped_size = grid.geometry.size
+	outlines = _outlines(rng, dewarped_size, 64)
+	W, H = SIZE
+	box = np.array([[0, 0], [W, 0], [W, H], [0, H], [0, 0]], dtype=np.float64)
+
+	# 1. the inverse map of all outlines in one launch == scipy's interpolator over the dense grid (incl. extrapolation)
+	flat = np.concatenate(outlines)
+	got_pts = grid.inverse(flat)
+	want_pts = ogrid.inverse(flat)
+	assert np.abs(got_pts - want_pts).max() < 1e-6
+
+	# 2. outline by outline: the reference's error for what lies off the page, else membership in outline ∩ page
+	rw = Rewarper(grid, SIZE)
+	ends = np.cumsum([len(c) for c in outlines])
+	n_clipped = n_outside = n_hull = 0
+	inside_ones = []
+	for c, e in zip(outlines, ends):
+		warped = _closed(want_pts[e - len(c):e])
+		valid = Geom("Polygon", [warped]).is_valid and not orings.ring_self_crosses(warped)
+		shape = warped if valid else convex_hull_ring(warped)
+		n_hull += not valid
+		touches = (shape[:, 0].max() > 0 and shape[:, 0].min() < W and shape[:, 1].max() > 0 and shape[:, 1].min() < H)
+		if not touches:
+			n_outside += 1
+			with pytest.raises(RuntimeError, match="failed to rewarp coords"):
+				rw(c)
+			continue
+		inside_ones.append(c)
+		out = rw(c)
+		assert np.array_equal(out[0], out[-1]) and len(out) >= 4
+		assert out[:, 0].min() >= 0 and out[:, 1].min() >= 0 and out[:, 0].max() <= W and out[:, 1].max() <= H
+		clipped = shape[:, 0].min() < 0 or shape[:, 1].min() < 0 or shape[:, 0].max() > W or shape[:, 1].max() > H
+		n_clipped += clipped
+		if not clipped:  # nothing to cut: the outline itself (GPU inverse map within 1e-6 of scipy's), whatever its start
+			def area(r):
+				return 0.5 * abs(float(np.sum(r[:-1, 0] * r[1:, 1] - r[1:, 0] * r[:-1, 1])))
+			assert abs(area(out) - area(shape)) <= 1e-6 * max(1.0, area(shape))
+			for v in out:
+				assert np.hypot(*(shape - v).T).min() < 1e-6
+			continue
+		lo, hi = shape.min(axis=0) - 5, shape.max(axis=0) + 5
+		single = None
+		for p in rng.uniform(lo, hi, size=(300, 2)):
+			if min(_distance_to_ring(shape, p), _distance_to_ring(box, p)) < 0.5:
+				continue
+			in_shape = orings.winding_number([tuple(q) for q in shape], p) != 0
+			in_page = 0 < p[0] < W and 0 < p[1] < H
+			in_out = orings.point_in_polygons([[out]], p)
+			if in_shape and in_page:
+				assert in_out  # nothing of outline ∩ page is lost
+			elif not in_page:
+				assert not in_out  # nothing outside the page ("no negative coordinates")
+			elif in_out and single is None:
+				single = False  # inside the page, outside the outline, inside the result: only a hull of several parts may
+		if single is False:
+			# the U: its two arms are separate parts, the result is their common hull (ref: compose.py:427-430)
+			hull = convex_hull_ring(out)
+			assert len(hull) == len(out) and Geom("Polygon", [out]).is_valid
+	assert n_outside >= 3 and n_clipped >= 8 and n_hull >= 1
+
+	# 3. many() == one call per outline
+	many = rw.many(inside_ones)
+	for c, m in zip(inside_ones, many):
+		assert np.array_equal(m, rw(c))

@@ -369,3 +369,64 @@ def test_ring_self_cross_reference_known_answers():
 	# a crossing 1e-9 away from a vertex is still found (exact arithmetic)
 	near = [(0, 0), (2, 2), (2, 0), (1e-9, 2), (0, 0)]
 	assert orings.ring_self_crosses(near)
+
+
+def _resize_exact(nodes, s):
+	"""The rule of SURVEY Appendix A.1 evaluated in float64 by plain numpy (a third, independent statement)."""
+	n = nodes.astype(np.float64)
+
+	def taps(size):
+		u = (np.arange(size * s) + 0.5) / s - 0.5
+		i = np.floor(u).astype(int)
+		f = u - i
+		f = np.where((i < 0) | (i >= size - 1), 0.0, f)
+		i = np.clip(i, 0, size - 1)
+		return i, np.minimum(i + 1, size - 1), f
+
+	h, w = n.shape[:2]
+	ix, ix1, fx = taps(w)
+	iy, iy1, fy = taps(h)
+	rows = n[:, ix] * (1 - fx)[None, :, None] + n[:, ix1] * fx[None, :, None]
+	return rows[iy] * (1 - fy)[:, None, None] + rows[iy1] * fy[:, None, None]
+
+
+@pytest.mark.parametrize("shape,cell,span", [((12, 9), 8, 6), ((40, 33), 25, 3), ((40, 33), 25, 6), ((7, 131), 9, 6)])
+def test_dense_grid_half_pixel_convention_agrees_with_torch_interpolate(shape, cell, span):
+	"""Two INDEPENDENT implementations of the same alignment rule (they do not pin cv2: PARITY UNPINNED stays,
+	DESIGN.md §2): torch.nn.functional.interpolate(mode="bilinear", align_corners=False) places output pixel X at
+	source position (X + 0.5) / s - 0.5 and clamps at the edges — what SURVEY Appendix A.1 says of
+	cv2.resize(INTER_LINEAR) and what oracle/cv.py restates —, and the same rule in float64 numpy.
+	What the comparison can show is the convention, not the last bits: a two-pass float32 lerp rounds four times at
+	the magnitude of the coordinate, and float32 resolves 4.9e-4 px between 4096 and 8192, so ANY two float32
+	implementations differ by up to ~3 ulp there (measured: oracle - exact 1.2e-3 px, torch - exact 1.1e-3 px,
+	oracle - torch 1.5e-3 px at x ~ 5700; 9e-5 px at x ~ 500).  The north star's 1e-3 px on the float grid is
+	therefore two float32 steps on a broadsheet page: it separates conventions (a half-pixel shift is 0.5 / s of a
+	cell, tens of pixels of difference between neighbouring nodes), not operation orders."""
+	import torch
+	import torch.nn.functional as F
+	h, w = shape
+	rng = np.random.default_rng(h * 100 + w)
+	gy, gx = np.mgrid[0:h, 0:w].astype(np.float64)
+	x = (gx - 1) * cell * span + 40 * np.sin(gy / 3.0) + rng.normal(0, 2, size=shape)
+	y = (gy - 1) * cell * span + 40 * np.cos(gx / 4.0) + rng.normal(0, 2, size=shape)
+	nodes = np.stack([x, y], axis=-1).astype(np.float32)
+	got = ocv.dense_grid(nodes, cell)
+	t = torch.from_numpy(nodes).permute(2, 0, 1).unsqueeze(0)  # (1, 2, h, w)
+	tor = F.interpolate(t, size=(h * cell, w * cell), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+	exact = _resize_exact(nodes, cell)
+	assert got.shape == tor.shape == exact.shape
+	step = float(np.spacing(np.float32(np.abs(exact).max())))  # one float32 step at the largest coordinate
+	assert np.abs(got - exact).max() <= 3 * step
+	assert np.abs(tor - exact).max() <= 3 * step
+	assert np.abs(got - tor).max() <= 4 * step
+	if np.abs(exact).max() < 4096:  # pages up to 4096 px: every pair within the north star's 1e-3 px
+		assert np.abs(got - tor).max() < 1e-3 and np.abs(got - exact).max() < 1e-3
+	# a different convention would be off by whole fractions of a cell: align_corners=True differs by > 1 px here
+	other = F.interpolate(t, size=(h * cell, w * cell), mode="bilinear", align_corners=True)[0].permute(1, 2, 0).numpy()
+	assert np.abs(got - other).max() > 1.0
+	# the structure the Transformer relies on (SURVEY §7 hard part 2): node g sits on pixel g * s + (s - 1) / 2 when
+	# s is odd, and the first / last s / 2 pixels are flat
+	if cell % 2:
+		c = (cell - 1) // 2
+		assert np.array_equal(got[c::cell, c::cell], nodes)
+	assert np.array_equal(got[0, 0], nodes[0, 0]) and np.array_equal(got[-1, -1], nodes[-1, -1])

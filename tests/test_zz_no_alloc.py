@@ -40,6 +40,29 @@ def test_noalloc_march_equals_march_twice_in_a_row(gpu):
 			assert np.isfinite(g).all()
 
 
+def test_noalloc_march_takes_no_device_memory(gpu):
+	"""hipMemGetInfo before and after: the call must not shrink the GPU's free memory (its buffers are part of the
+	library's device image, loaded with the first launch), while ogd_march_grid on a grid larger than anything its
+	block cache holds does."""
+	import ctypes
+	lib = gpu.load()
+
+	def free_bytes():
+		f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+		gpu.check(lib.ogd_mem_info(ctypes.byref(f), ctypes.byref(t)))
+		return f.value
+
+	args = (0.0, np.pi / 2, (0, 0, 500, 500), 1, 500, 500, 2)
+	gpu.march_grid(*args, noalloc=True)  # module, scratch address and kernels are loaded now
+	gpu.check(lib.ogd_trim(None))
+	before = free_bytes()
+	for _ in range(3):
+		gpu.march_grid(*args, noalloc=True)
+		assert free_bytes() >= before
+	gpu.march_grid(*args)  # the allocating form takes 2 x 2 MB for the same grids
+	assert free_bytes() < before
+
+
 def test_noalloc_march_rejects_grids_beyond_its_scratch(gpu):
 	with pytest.raises(gpu.OgdError, match="exceed the fixed scratch"):
 		gpu.march_grid(0.0, np.pi / 2, (0, 0, 100, 100), 1, 600, 600, 2, noalloc=True)
