@@ -43,17 +43,30 @@ N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is 
 N_POLYGONS = 400
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
-TRAFFIC_JSON = ROOT / "profiles" / "r02" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh)
+TRAFFIC_JSON = ROOT / "profiles" / "r03" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh, tools/k2_traffic.py)
+K2_SOURCES = ("ogd_remap_lds.h", "ogd_remap.hip", "ogd_remap_math.h")  # what the K2 kernel is compiled from
+
+
+def k2_source_hash():
+	import hashlib
+	digest = hashlib.sha256()
+	for name in K2_SOURCES:
+		digest.update((ROOT / "origami_amd" / "csrc" / name).read_bytes())
+	return digest.hexdigest()
 
 
 def measured_traffic(k2_bytes):
-	"""HBM bytes per K2 launch from the committed PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
-	gfx950 correction applied there) — only if they were taken on this same launch shape."""
+	"""HBM bytes per K2 launch from the committed PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs — PMC
+	counters cannot be read from inside this process —, gfx950 correction applied there).  Only if they were taken on
+	THIS kernel: same instantiation, same launch shape and the same source files (their hash is stored with the
+	counters); anything else reports null rather than a number measured on other code."""
 	try:
 		t = json.loads(TRAFFIC_JSON.read_text())
 	except (OSError, ValueError):
 		return None
 	if t.get("kernel") != K2_KERNEL or t.get("algorithmic_bytes_per_launch") != k2_bytes:
+		return None
+	if t.get("source_sha256") != k2_source_hash():
 		return None
 	return t["hbm_bytes_per_launch"]
 
@@ -66,6 +79,7 @@ def parse_args():
 	ap.add_argument("--pages", type=int, default=64, help="pages per batch and GPU")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="skip the host-ring pipeline leg (configs[2])")
+	ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[3] / configs[4] kernel legs and the batch-CLI stage leg")
 	ap.add_argument("--pipeline-jobs", type=int, default=0, help="page jobs per GPU in the pipeline leg (0 = 2 x pages)")
 	ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
 	ap.add_argument("--harness-selftest", action="store_true",
@@ -193,7 +207,7 @@ def verify(torch, wl):
 		raise SystemExit("bench: GPU output differs from the oracle on the verification crop")
 
 
-def cpu_baseline(wl, threads, budget_s=12.0):
+def cpu_baseline(wl, threads, budget_s=9.0, single_budget_s=3.0):
 	"""The CPU restatement of the same path (oracle: C/OpenMP resize + remap, scipy interpolants)
 	timed on a bounded sample of the same batch: pages 0, 1, ... (dense grid + remap + the page's 400
 	contour rings each) until about `budget_s` seconds of CPU work are done."""
@@ -221,10 +235,27 @@ def cpu_baseline(wl, threads, budget_s=12.0):
 		spent += t2 - t0
 		mp += out.shape[0] * out.shape[1] / 1e6
 		n += 1
+	# the same on ONE thread (SURVEY 8d asks for both counts): pages 0, 1, ... for about single_budget_s seconds
+	s_spent = s_mp = 0.0
+	s_n = 0
+	while s_spent < single_budget_s and s_n < wl["pages"].shape[0]:
+		grid = grids[s_n % len(wl["warps"])] if s_n % len(wl["warps"]) in grids else None
+		if grid is None:
+			break
+		page = wl["pages"][s_n].cpu().numpy()
+		t0 = time.perf_counter()
+		grid._full = None
+		out = ocv.remap_u8(page, grid.points_full(1), ocv.INTER_LINEAR, 1)
+		odw.transform_rings(grid.transformer, wl["polys"][s_n]["rings"])
+		s_spent += time.perf_counter() - t0
+		s_mp += out.shape[0] * out.shape[1] / 1e6
+		s_n += 1
 	return dict(
 		value=round(mp / spent, 2), unit="MP/s", cores=threads, kind="port",
 		sample="%d pages 6000x8000 gray of the batch in %.1f s: dense grid + remap %.2f s (C/OpenMP oracle, %d threads) + %d contour rings/page %.2f s (scipy, 1 thread)" % (
-			n, spent, t_pix, threads, len(wl["polys"][0]["rings"]), t_pts))
+			n, spent, t_pix, threads, len(wl["polys"][0]["rings"]), t_pts),
+		single_thread=dict(value=round(s_mp / max(s_spent, 1e-9), 2), unit="MP/s", cores=1,
+			sample="%d pages of the same batch in %.1f s, everything on one thread" % (s_n, s_spent)))
 
 
 def pipeline_leg(torch, wl, n_jobs, barrier, streams, slots=3):
@@ -272,6 +303,235 @@ def pipeline_leg(torch, wl, n_jobs, barrier, streams, slots=3):
 	up = n_jobs * H * W
 	down = n_jobs * Hd * Wd + sum(wl["polys"][j % n_pages]["n"] for j in range(n_jobs)) * 16
 	return elapsed, up, down
+
+
+def _event_time(torch, launch, iters, warm=3):
+	"""Average duration in ms of `launch` (which enqueues on torch's current stream) by HIP events on that stream."""
+	for _ in range(warm):
+		launch()
+	torch.cuda.synchronize()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record()
+	for _ in range(iters):
+		launch()
+	e1.record()
+	torch.cuda.synchronize()
+	return e0.elapsed_time(e1) / iters
+
+
+def _kernel_entry(ms, nbytes, what):
+	gbs = nbytes / (ms * 1e-3) / 1e9
+	return {"what": what, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+		"achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def config3_leg(torch, lib, check, dev, stream, iters=20):
+	"""BASELINE.json configs[3], the bandwidth-stress config: a 6000x8000 RGB page and a 4-class label map (1280x2400,
+	nearest, through the grid scaled to the label map: Dewarper.dewarp_image) through a fine 8-px node grid.  Device-
+	resident, HIP events on the launch stream, each kernel against its OWN algorithmic bytes: K2 RGB
+	Hd*Wd*(8+3) + H*W*3 (14 B/px), fused RGB Hd*Wd*3 + H*W*3 + h*w*8 (~6 B/px), label K2 Hd*Wd*9 + h1*w1.  A crop of
+	every output is checked against the oracle first."""
+	from oracle import cv as ocv
+	from origami_amd import synth
+	W, H = PAGE
+	cell = 8
+	rng = np.random.default_rng(3000)
+	nodes = synth.Warp((W, H), 0.03, 0.02, 2, 1).node_grid(cell)
+	h, w = nodes.shape[:2]
+	Hd, Wd = h * cell, w * cell
+	rgb = synth.text_page(rng, (W, H), channels=3)
+	labels = synth.label_map(rng, (1280, 2400), 4, blocks=64)
+	h1, w1 = labels.shape
+	sx, sy = float(np.float32(w1 / W)), float(np.float32(h1 / H))
+	d_nodes = torch.from_numpy(nodes).to(dev)
+	d_rgb = torch.from_numpy(rgb).to(dev)
+	d_lab = torch.from_numpy(labels).to(dev)
+	d_map = torch.empty((Hd, Wd, 2), dtype=torch.float32, device=dev)
+	d_out3 = torch.empty((Hd, Wd, 3), dtype=torch.uint8, device=dev)
+	d_out1 = torch.empty((Hd, Wd), dtype=torch.uint8, device=dev)
+	n = 19 * cell  # dense pixels < 19 * cell only use node rows / columns 0..19 (verify())
+	crop = nodes[:20, :20]
+
+	def grid(sx_, sy_):
+		check(lib.ogd_grid_fill_dev(d_nodes.data_ptr(), h, w, cell, sx_, sy_, d_map.data_ptr(), stream))
+
+	def k2_rgb():
+		check(lib.ogd_remap_u8_dev(d_rgb.data_ptr(), H, W, 3, 3 * W, d_map.data_ptr(), Hd, Wd, d_out3.data_ptr(), 3 * Wd, 1, stream))
+
+	def fused_rgb():
+		check(lib.ogd_dewarp_u8_dev(d_rgb.data_ptr(), H, W, 3, 3 * W, d_nodes.data_ptr(), h, w, cell, 1.0, 1.0, d_out3.data_ptr(), 3 * Wd, 1, stream))
+
+	def k2_labels():
+		check(lib.ogd_remap_u8_dev(d_lab.data_ptr(), h1, w1, 1, w1, d_map.data_ptr(), Hd, Wd, d_out1.data_ptr(), Wd, 0, stream))
+
+	def fused_labels():
+		check(lib.ogd_dewarp_u8_dev(d_lab.data_ptr(), h1, w1, 1, w1, d_nodes.data_ptr(), h, w, cell, sx, sy, d_out1.data_ptr(), Wd, 0, stream))
+
+	out = {"what": "configs[3]: 6000x8000 RGB page + 4-class label map 1280x2400 (nearest, scaled grid) through an 8-px node grid %dx%d, dense %dx%d; device-resident, HIP events, %d launches each" % (w, h, Wd, Hd, iters)}
+	want_rgb = ocv.remap_u8(rgb, ocv.dense_grid(crop, cell))[:n, :n]
+	dense_l = ocv.dense_grid(crop, cell)
+	dense_l[:, :, 0] *= np.float32(sx)
+	dense_l[:, :, 1] *= np.float32(sy)
+	want_lab = ocv.remap_u8(labels, dense_l, ocv.INTER_NEAREST)[:n, :n]
+	grid(1.0, 1.0)
+	for name, fn in (("k2_rgb", k2_rgb), ("fused_rgb", fused_rgb)):
+		d_out3.zero_()
+		fn()
+		torch.cuda.synchronize()
+		if not np.array_equal(d_out3[:n, :n].cpu().numpy(), want_rgb):
+			raise SystemExit("bench: %s differs from the oracle on the verification crop" % name)
+	out["k2_rgb"] = _kernel_entry(_event_time(torch, k2_rgb, iters), Hd * Wd * (8 + 3) + H * W * 3, "ogd_remap_u8_dev, C = 3, linear (14 B/px)")
+	out["fused_rgb"] = _kernel_entry(_event_time(torch, fused_rgb, iters), Hd * Wd * 3 + H * W * 3 + h * w * 8, "ogd_dewarp_u8_dev, C = 3, linear (no dense map: ~6 B/px; VALU-bound)")
+	grid(sx, sy)
+	for name, fn in (("k2_labels", k2_labels), ("fused_labels", fused_labels)):
+		d_out1.zero_()
+		fn()
+		torch.cuda.synchronize()
+		if not np.array_equal(d_out1[:n, :n].cpu().numpy(), want_lab):
+			raise SystemExit("bench: %s differs from the oracle on the verification crop" % name)
+	out["k2_labels_nearest"] = _kernel_entry(_event_time(torch, k2_labels, iters), Hd * Wd * 9 + h1 * w1, "ogd_remap_u8_dev, label map, nearest, grid scaled to the label map (9 B/px)")
+	out["fused_labels_nearest"] = _kernel_entry(_event_time(torch, fused_labels, iters), Hd * Wd + h1 * w1 + h * w * 8, "ogd_dewarp_u8_dev, label map, nearest (Dewarper.dewarp_image)")
+	out["k1a_cell8"] = _kernel_entry(_event_time(torch, lambda: grid(1.0, 1.0), iters), Hd * Wd * 8 + h * w * 8, "ogd_grid_fill_dev, cell 8 (8 B/px)")
+	return out
+
+
+def config4_leg(torch, lib, check, dev, stream, iters=20):
+	"""BASELINE.json configs[4], the grid-fill + polygon-warp stress: a heavily warped 6000x8000 page (A = B = 0.12 rad)
+	with 2000 h / 3000 v flow samples and 5000 contour rings.  Timed: Grid.create (two angle fields + the march on
+	the device, wall clock), the transformer build, K3 over all rings (HIP events; points/s), K1b rasterising the h
+	angle field on the page's pixel lattice (the north star's kernel (1); f32 out, 4 B/px)."""
+	from origami_amd import synth
+	from origami_amd.dewarp import Grid
+	W, H = PAGE
+	rng = np.random.default_rng(4000)
+	warp = synth.Warp((W, H), 0.12, 0.12, 1, 2)
+	samples_h, samples_v = synth.flow_samples(rng, warp, 2000, 3000)
+
+	class _Page:
+		@staticmethod
+		def size(dewarped):
+			return (W, H)
+
+	Grid.create(_Page, samples_h, samples_v, grid_res=CELL)  # first-use costs
+	t0 = time.perf_counter()
+	reps = 3
+	for _ in range(reps):
+		grid = Grid.create(_Page, samples_h, samples_v, grid_res=CELL)
+	t_grid = (time.perf_counter() - t0) / reps
+	t0 = time.perf_counter()
+	tf = grid.transformer
+	t_tf = time.perf_counter() - t0
+	rings = synth.polygon_rings(rng, (W, H), 5000, integer_scale=W / 1280, valid=False)
+	off = np.zeros(len(rings) + 1, dtype=np.int64)
+	np.cumsum([len(r) for r in rings], out=off[1:])
+	pieces = np.unique(np.concatenate([np.arange(a, b, 64) for a, b in zip(off[:-1], off[1:])] + [off[-1:]])).astype(np.int64)
+	flat = np.concatenate(rings)
+	q = torch.from_numpy(flat).to(dev)
+	o = torch.from_numpy(pieces).to(dev)
+	res = torch.empty((len(flat), 2), dtype=torch.float64, device=dev)
+	inner, extra = tf._interp.triangulations
+	bounds = np.array(tf._interp.bounds, dtype=np.float64)
+
+	def k3():
+		check(lib.ogd_tri_eval_ragged_dev(
+			inner.handle, extra.handle, bounds.ctypes.data, q.data_ptr(), o.data_ptr(), len(pieces) - 1, res.data_ptr(), stream))
+
+	ms_k3 = _event_time(torch, k3, iters)
+	if bool(torch.isnan(res).any()):
+		raise SystemExit("bench: K3 produced NaN")
+	want = tf.transform_table(flat[:4096], np.array([0, 4096], dtype=np.int64))  # the host entry point on a sample
+	if not np.array_equal(res[:4096].cpu().numpy(), want):
+		raise SystemExit("bench: K3 device launch differs from the host entry point")
+
+	fi, fe = samples_field(samples_h, (W, H))
+	nx, ny = W + 1, H + 1
+	lattice = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+	fb = np.array([0, 0, W, H], dtype=np.float64)
+
+	def k1b():
+		check(lib.ogd_tri_rasterize_dev(
+			fi.handle if fi is not None else None, fe.handle, fb.ctypes.data, 0.0, 0.0, 1.0, nx, ny, lattice.data_ptr(), 1, nx, 0, stream))
+
+	ms_k1b = _event_time(torch, k1b, max(3, iters // 4), warm=1)
+	h, w = grid.points("sample").shape[:2]
+	return {
+		"what": "configs[4]: heavily warped 6000x8000 page (A = B = 0.12 rad), 2000 h + 3000 v flow samples, 5000 contour rings (%d points), node grid %dx%d" % (len(flat), w, h),
+		"grid_create_ms": round(t_grid * 1e3, 2),
+		"transformer_build_ms": round(t_tf * 1e3, 2),
+		"k3": {"what": "ogd_tri_eval_ragged_dev, one wavefront per <= 64-vertex ring piece (%d pieces), HIP events" % (len(pieces) - 1),
+			"avg_launch_us": round(ms_k3 * 1e3, 2), "points": int(len(flat)), "Gpoints_per_s": round(len(flat) / ms_k3 / 1e6, 3),
+			"algorithmic_bytes_per_launch": int(len(flat) * 32), "achieved_GBs": round(len(flat) * 32 / ms_k3 / 1e6, 1),
+			"bound": "latency (~5 dependent loads per query), not bandwidth"},
+		"k1b": {"what": "ogd_tri_rasterize_dev, h angle field (2000 samples) on the %dx%d pixel lattice, f32 out" % (nx, ny),
+			"avg_launch_ms": round(ms_k1b, 4), "Gpx_per_s": round(nx * ny / ms_k1b / 1e6, 1),
+			"algorithmic_bytes_per_launch": int(nx * ny * 4), "achieved_GBs": round(nx * ny * 4 / ms_k1b / 1e6, 1),
+			"frac_of_hbm_peak": round(nx * ny * 4 / ms_k1b / 1e6 / HBM_PEAK_GBS, 4), "bound": "fp64 instruction stream"},
+	}
+
+
+def samples_field(samples, size):
+	"""(inner, extra) triangulations of the angle interpolant of flow samples (what Field builds, ref: dewarp.py:108-116)."""
+	from origami_amd.lingrid import lininterp
+	interp = lininterp(samples.points, samples.values, (0, 0, size[0], size[1]))
+	samples_field.keep = interp  # the handles live as long as the interpolator
+	return interp.triangulations
+
+
+def stage_leg(n_gpus, n_pages=96, workers=(1, 8), n_polygons=400):
+	"""Throughput (iii) of SURVEY 8d: the REAL `dewarp` batch CLI (python -m origami_amd.batch.detect.dewarp: directory
+	walk, zip / WKT I/O, flow samples -> node grid -> transformer -> contours, dewarp.zip + contours.1.zip written) on
+	`n_pages` generated 6000x8000 page directories, as a child process, once per worker count (`--gpus n_gpus
+	--workers-per-gpu k`); wall clock of the whole command, process start-up and HIP context creation included.
+	MP/s counts the pages' pixels (the stage itself writes the grid, not pixels).  Never `value`."""
+	import shutil
+	import subprocess
+	import tempfile
+	from origami_amd import synth
+	W, H = PAGE
+	root = Path(tempfile.mkdtemp(prefix="ogd_bench_stage_"))
+	out = {"what": "dewarp batch CLI end to end on %d generated 6000x8000 page directories (%d contour polygons, 1500 + 2000 flow samples each), child process, wall clock incl. start-up; per worker count" % (n_pages, n_polygons), "runs": []}
+	try:
+		rng = np.random.default_rng(5000)
+		first = synth.write_page_dir(root, "page0000", rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_polygons)
+		for k in range(1, n_pages):
+			page = root / ("page%04d.png" % k)
+			try:
+				os.link(first, page)  # the stage reads only the page's size
+			except OSError:
+				shutil.copyfile(first, page)
+			synth.write_page_inputs(page, rng, size=(W, H), n_h=1500, n_v=2000, n_regions=n_polygons)
+		env = dict(os.environ)
+		env.pop("RANK", None), env.pop("LOCAL_RANK", None), env.pop("WORLD_SIZE", None)
+		empty = Path(tempfile.mkdtemp(prefix="ogd_bench_stage1_"))  # a tree of its own: the stage walks `root` recursively
+		for k in workers:
+			cmd = [sys.executable, "-m", "origami_amd.batch.detect.dewarp", str(root), "--lock-strategy", "NONE", "--plain",
+				"--overwrite", "--gpus", str(n_gpus), "--workers-per-gpu", str(k)]
+			# the same command on ONE page: interpreter + imports + worker spawn + HIP context creation, i.e. what the
+			# command costs before its page rate counts (a job of 10 000 pages pays it once)
+			one = [c if c != str(root) else str(empty) for c in cmd]
+			if not (empty / "page0000.png").exists():
+				os.link(first, empty / "page0000.png")
+				shutil.copytree(root / "page0000.out", empty / "page0000.out")
+			t0 = time.perf_counter()
+			subprocess.run(one, cwd=str(ROOT), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+			t_start = time.perf_counter() - t0
+			t0 = time.perf_counter()
+			r = subprocess.run(cmd, cwd=str(ROOT), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+			dt = time.perf_counter() - t0
+			done = sum((root / ("page%04d.out" % i) / "contours.1.zip").exists() for i in range(n_pages))
+			if r.returncode != 0 or done != n_pages:
+				out["runs"].append({"workers_per_gpu": k, "error": r.stdout.decode(errors="replace")[-400:]})
+				continue
+			steady = max(dt - t_start, 1e-9) / max(n_pages - 1, 1)
+			out["runs"].append({"gpus": n_gpus, "workers_per_gpu": k, "seconds": round(dt, 3),
+				"ms_per_page": round(dt / n_pages * 1e3, 2), "MP_per_s": round(n_pages * W * H / 1e6 / dt, 1),
+				"one_page_run_seconds": round(t_start, 3), "ms_per_page_beyond_the_first": round(steady * 1e3, 2),
+				"MP_per_s_beyond_the_first": round(W * H / 1e6 / steady, 1)})
+	finally:
+		shutil.rmtree(root, ignore_errors=True)
+		if "empty" in locals():
+			shutil.rmtree(empty, ignore_errors=True)
+	return out
 
 
 def launch_ranks(n):
@@ -469,6 +729,19 @@ def main():
 		if not args.no_cpu_baseline and world == 1:
 			threads = args.cpu_threads or min(16, os.cpu_count() or 1)
 			line["cpu_baseline"] = cpu_baseline(wl, threads)
+		if not args.no_extra_legs:
+			# Per-config kernel legs (single-GPU configs: at N = 1 only) and the batch CLI (iii).  A parity failure
+			# ends the run without a line (SystemExit); any other trouble is reported in the leg, not fatal.
+			if world == 1:
+				for key, leg in (("configs3", config3_leg), ("configs4", config4_leg)):
+					try:
+						line[key] = leg(torch, lib, check, dev, stream)
+					except Exception as e:  # noqa: BLE001
+						line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+			try:
+				line["stage"] = stage_leg(world, workers=(1, 8) if world == 1 else (4,))
+			except Exception as e:  # noqa: BLE001
+				line["stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
 		print(json.dumps(line), flush=True)
 	if world > 1:
 		dist.barrier()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes profiles/r02/k2_traffic.json from two rocprofv3 --pmc passes over tools/kbench (tools/pmc.sh):
+"""Writes profiles/r03/k2_traffic.json from two rocprofv3 --pmc passes over tools/kbench (tools/pmc.sh):
     bash tools/pmc.sh fetch "library ogd_remap" FETCH_SIZE TCC_EA0_RDREQ_32B_sum
     bash tools/pmc.sh write "library ogd_remap" WRITE_SIZE
     python tools/k2_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write
@@ -45,6 +45,11 @@ out = {
 	"hbm_bytes_per_launch": int(round(fetch_kb * 1024 * 2 + write_kb * 1024)),
 	"algorithmic_bytes_per_launch": Hd * Wd * 9 + H * W,
 }
-p = Path(__file__).resolve().parent.parent / "profiles" / "r02" / "k2_traffic.json"
+# bench.py reports these counters only for the source they were measured on
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import bench  # noqa: E402
+out["source_files"] = list(bench.K2_SOURCES)
+out["source_sha256"] = bench.k2_source_hash()
+p = Path(__file__).resolve().parent.parent / "profiles" / "r03" / "k2_traffic.json"
 p.write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))
