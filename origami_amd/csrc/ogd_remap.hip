@@ -35,20 +35,35 @@ static int check_image(int H, int W, int C, ptrdiff_t stride, const char* what) 
 // has the smaller source window per pixel and fewer x taps / lerped node rows to build per pixel.
 // LDSW_MC: LDS bytes per wavefront for 3 / 4 channels (6 KB: six wavefronts per SIMD; the 32 x 32 tile of the
 // fused kernel needs 8 KB for its ~40-row window).
-template <class MapSrc> struct TileShape { static constexpr int LX = 16, RPT = 2, LDSW_MC = 6144; };
-template <> struct TileShape<MapNodes> { static constexpr int LX = 8, RPT = 4, LDSW_MC = 8192; };
-template <> struct TileShape<MapNodesUnit> : TileShape<MapNodes> {};
+// Multi-channel K2 (RGB / RGBA pages, configs[3]): experiment switches, see tools/build_variant.sh
+#ifndef K2MC_LX
+#define K2MC_LX 16
+#endif
+#ifndef K2MC_RPT
+#define K2MC_RPT 2
+#endif
+#ifndef K2MC_LDSW
+#define K2MC_LDSW 6144
+#endif
+template <class MapSrc, int C> struct TileShape { static constexpr int LX = 16, RPT = 2, LDSW = 4096; };
+#ifndef K2C3_LDSW
+#define K2C3_LDSW 8192  // with RL_SHEAR3 only: the sheared three-channel window needs a 504-byte pitch
+#endif
+template <> struct TileShape<MapGlobal, 3> { static constexpr int LX = K2MC_LX, RPT = K2MC_RPT, LDSW = RL_SHEAR3 ? K2C3_LDSW : K2MC_LDSW; };
+template <> struct TileShape<MapGlobal, 4> { static constexpr int LX = K2MC_LX, RPT = K2MC_RPT, LDSW = K2MC_LDSW; };
+template <int C> struct TileShape<MapNodes, C> { static constexpr int LX = 8, RPT = 4, LDSW = C == 1 ? 4096 : 8192; };
+template <int C> struct TileShape<MapNodesUnit, C> : TileShape<MapNodes, C> {};
 
 template <int C, class MapSrc>
 static void launch_remap(int interp, hipStream_t st, const uint8_t* src, int H, int W, ptrdiff_t ss,
                          const MapSrc& ms, int Hd, int Wd, uint8_t* dst, ptrdiff_t ds) {
-  constexpr int LX = TileShape<MapSrc>::LX, RPT = TileShape<MapSrc>::RPT;
+  constexpr int LX = TileShape<MapSrc, C>::LX, RPT = TileShape<MapSrc, C>::RPT;
   constexpr int TW = 4 * LX, TH = (64 / LX) * RPT;
-  constexpr int LDSW = C == 1 ? 4096 : TileShape<MapSrc>::LDSW_MC;  // source window budget per wavefront
+  constexpr int LDSW = TileShape<MapSrc, C>::LDSW;  // source window budget per wavefront
   // sheared tiles (ogd_remap_lds.h:rl_shear): rows begin up to `reach` columns left of their tile's nominal origin
   int step = 0, wrap = 0, bias = 0, reach = 0;
-  if (MapSrc::SHEAR && C == 1) {
-    step = (int)(((ds % 64) + 64) % 64);
+  if (MapSrc::SHEAR && rl_shear_channels(C)) {
+    step = (int)((((ds % 64) + 64) % 64) * RL_SHEAR_INV(C) % 64);
     if (step >= 32) step -= 64;
     wrap = std::abs(step) * (TH - 1) >= 64;
     bias = (wrap || step < 0) ? 64 : 0;

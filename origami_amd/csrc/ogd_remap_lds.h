@@ -27,6 +27,7 @@ namespace ogd {
 typedef float rl_f4 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t rl_u32u __attribute__((aligned(1)));
 typedef uint16_t rl_u16u __attribute__((aligned(1)));
+typedef uint64_t rl_u64u __attribute__((aligned(1)));
 typedef short rl_s2 __attribute__((ext_vector_type(2)));
 
 // Pointers that arrive inside a by-value struct lose their address space (hipcc then emits flat loads);
@@ -86,6 +87,7 @@ __device__ __forceinline__ void rl_wave_reduce_minmax(int& mn, int& mx) {
 // K2 proper: the dense map materialised in memory ([Hd][Wd] float2).
 struct MapGlobal {
   static constexpr bool SHEAR = true;  // one-channel tiles are sheared onto the sectors of the output (see the kernel)
+  static constexpr bool STAGE_QW = true;  // 64-pixel tiles: multi-channel window rows are staged in 8-byte pieces
   const float* __restrict__ map;
   int Hd, Wd;
 
@@ -128,6 +130,7 @@ struct MapGlobal {
 template <bool UNIT>
 struct MapNodesT {
   static constexpr bool SHEAR = false;  // the map of a tile is built per tile column: rectangular tiles only
+  static constexpr bool STAGE_QW = false;  // 32-pixel tiles: a window row is <= 32 dwords already (measured: 120 -> 125 us with 8-byte pieces)
   const float2* __restrict__ nodes;
   int h, w;
   double inv_s;
@@ -249,6 +252,23 @@ typedef MapNodesT<true> MapNodesUnit;
 // sh0 comes from the tile row, d(rr) = rr * step while that stays within a sector's length (step = stride mod 64,
 // taken from [-32, 32)), else its residue in [-32, 32) — the rows of a tile then lie within 64 columns of each other
 // and the source window grows by that much at most.  Every row is still cut into consecutive TW-column pieces.
+// Three channels: a row piece is 64 pixels = 192 bytes = three sectors once it begins on one, i.e. once
+// address + 3 * column = 0 (mod 64); 3 is invertible mod 64 (3 * 43 = 129), so the shift in PIXELS that does it is
+// a = 43 * address (mod 64), and it drifts from row to row by 43 * stride (mod 64) — the same walk as for one channel
+// with the byte address replaced by 43 times it.  (Map and output then align together: the map address of a pixel is
+// 8 * its index, and index = 0 (mod 64) is what both conditions say.)  Four channels would leave a 16-pixel walk
+// ((address / 4) mod 16); not done.
+// MEASURED AND SWITCHED OFF (profiles/r03/e_rgb_shear.log): same bytes (the stride / alignment tests run with it), but
+// K2 RGB 143 -> 169-190 us.  The parallelogram is 35-56 pixels wider than the tile, and where the source window of a
+// one-channel tile grows by a few dozen BYTES (the source is a tenth of K2's traffic), a three-channel window grows
+// 1.5-1.9x on a source that is a fifth of the traffic and is staged dword by dword: the sectors saved on the
+// output (WRITE_SIZE is only 3.8 % above the output's own size for RGB) do not pay for it.
+#ifndef RL_SHEAR3
+#define RL_SHEAR3 0
+#endif
+__host__ __device__ constexpr bool rl_shear_channels(int C) { return C == 1 || (RL_SHEAR3 && C == 3); }
+#define RL_SHEAR_INV(C) ((C) == 3 ? 43u : 1u)
+
 __device__ __forceinline__ int rl_shear(int sh0, int step, int wrap, int rr) {
   const int d = rr * step;
   return sh0 + (wrap ? ((d + 32) & 63) - 32 : d);
@@ -286,7 +306,10 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 #ifndef RL_W1B
 #define RL_W1B 6
 #endif
-#define RL_WAVES_PER_SIMD(C, RPT) ((C) == 1 ? ((RPT) <= 2 ? 8 : RL_W1B) : 5)
+#ifndef RL_WMC
+#define RL_WMC 5
+#endif
+#define RL_WAVES_PER_SIMD(C, RPT) ((C) == 1 ? ((RPT) <= 2 ? 8 : RL_W1B) : RL_WMC)
 // Wavefronts per workgroup (neighbouring tiles of one tile row): 4; tools/kbench builds other values to measure
 #ifndef RL_WPB
 #define RL_WPB 4
@@ -296,13 +319,14 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
     const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
     uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb, int sh_step = 0, int sh_wrap = 0, int sh_bias = 0) {
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
-  constexpr bool SHEAR = MapSrc::SHEAR && C == 1;
+  constexpr bool SHEAR = MapSrc::SHEAR && rl_shear_channels(C);
   constexpr int TAPS = LIN ? 2 : 1;
   constexpr int SHIFT = LIN ? 5 : 0;
   constexpr int RW = 64 / LX;   // output rows per wave pass
   constexpr int TH = RW * RPT;  // tile height
   constexpr int TW = 4 * LX;    // tile width
-  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * 5) / 4 + (TAPS + 6) * C + 3) & ~3;  // LDS pitch (bytes)
+  // LDS pitch (bytes): a multiple of 4, of 8 for three / four channels (their windows are staged in 8-byte pieces)
+  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * 5) / 4 + (TAPS + 6) * C + (C == 1 ? 3 : 7)) & (C == 1 ? ~3 : ~7);
   constexpr int MAXROWS = LDSW / PF;
   // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
   constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   int Xr[RPT];  // column of the lane's first pixel in row pass r
   int sh0 = 0;
   if (SHEAR) {
-    sh0 = (int)((reinterpret_cast<uintptr_t>(dst) + (ptrdiff_t)(by * TH) * ds) & 63) + sh_bias;
+    sh0 = (int)(((reinterpret_cast<uintptr_t>(dst) + (ptrdiff_t)(by * TH) * ds) * RL_SHEAR_INV(C)) & 63) + sh_bias;
     bool any = false;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -398,11 +422,47 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
 #ifndef RL_STAGE_U
 #define RL_STAGE_U 8
 #endif
-    constexpr int U = RL_STAGE_U;
-    const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
-    const int r0 = lane >> sh;
+#ifndef RL_STAGE_QW
+#define RL_STAGE_QW 1
+#endif
+#ifndef RL_STAGE_UQ
+#define RL_STAGE_UQ 8  // 8-byte pieces in flight per lane
+#endif
+    // three / four channels: a window row is 50-70 dwords, i.e. one row per pass of the wavefront, and a 64 x 8 tile's
+    // window has 11-13 rows: 12 loads in flight per lane stage it in ONE round trip (8: two)
+#ifndef RL_STAGE_U_MC
+#define RL_STAGE_U_MC 12
+#endif
+    constexpr int U = C == 1 ? RL_STAGE_U : RL_STAGE_U_MC;
     const uint8_t* pw = src + ((ptrdiff_t)mny * ss + x0b);  // wave-uniform base + 32-bit lane offsets
     const uint32_t ss32 = (uint32_t)ss;                      // the window lies inside the image: ss > 0
+    if (RL_STAGE_QW && MapSrc::STAGE_QW && C > 1 && x0b + 8 * ((wbytes + 7) >> 3) <= WB) {  // wave-uniform
+      // three / four channels: window rows of 50-70 dwords are staged as 8-byte pieces — half the loads and LDS
+      // writes, and 26-35 pieces per row let the wavefront take two rows per pass (PF is a multiple of 8 and the
+      // slice 16-byte aligned; global loads need no more than their dword alignment)
+      static_assert(C == 1 || PF % 8 == 0, "8-byte window pieces need an 8-byte pitch");
+      const int P8 = (wbytes + 7) >> 3;
+      const int sh = P8 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
+      const int r0 = lane >> sh;
+      uint64_t* win8 = reinterpret_cast<uint64_t*>(win);
+      for (int c = lane & (cw - 1); c < P8; c += cw) {
+        for (int rb = 0; rb < nrows; rb += RL_STAGE_UQ * rp) {  // wave-uniform trip count
+          uint64_t v[RL_STAGE_UQ];
+#pragma unroll
+          for (int u = 0; u < RL_STAGE_UQ; ++u) {
+            const uint32_t row = (uint32_t)min(rb + r0 + u * rp, nrows - 1);
+            v[u] = *reinterpret_cast<const rl_u64u*>(pw + (__umul24(row, ss32) + 8u * (uint32_t)c));
+          }
+#pragma unroll
+          for (int u = 0; u < RL_STAGE_UQ; ++u) {
+            const int row = min(rb + r0 + u * rp, nrows - 1);
+            win8[__mul24(row, PF / 8) + c] = v[u];
+          }
+        }
+      }
+    } else {
+    const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
+    const int r0 = lane >> sh;
     for (int c = lane & (cw - 1); c < P4; c += cw) {
       for (int rb = 0; rb < nrows; rb += U * rp) {  // wave-uniform trip count
         // rows past the window re-read and re-write its last row (same bytes): no predication
@@ -418,6 +478,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
           win[__mul24(row, PF / 4) + c] = v[u];
         }
       }
+    }
     }
   } else {
     const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;

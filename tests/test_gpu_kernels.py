@@ -157,15 +157,17 @@ def test_remap_strided_source_and_tiny_images(gpu):
 	np.testing.assert_array_equal(gpu.remap_u8(one, m1, 0), ocv.remap_u8(one, m1, 0))
 
 
-def test_remap_dev_into_any_stride_and_alignment(gpu):
+@pytest.mark.parametrize("C", [1, 3])
+def test_remap_dev_into_any_stride_and_alignment(gpu, C):
 	"""K2 cuts every output row into pieces that begin on 64-byte sectors of the output ADDRESS (sheared tiles,
-	ogd_remap_lds.h:rl_shear): every residue of the row stride mod 64 (drifting rows as well as rows that wrap),
-	misaligned buffers, outputs narrower than a tile and wider than several; nothing outside the rows is written."""
+	ogd_remap_lds.h:rl_shear; one and three channels): every residue of the row stride mod 64 (drifting rows as well
+	as rows that wrap), misaligned buffers, outputs narrower than a tile and wider than several; nothing outside the
+	rows is written."""
 	lib = gpu.load()
 	rng = np.random.default_rng(64)
 	H, W = 120, 150
-	src = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
-	cap = 64 * 1024
+	src = rng.integers(0, 256, size=(H, W) if C == 1 else (H, W, C), dtype=np.uint8)
+	cap = 64 * 1024 * C
 	d_src, d_map, d_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
 	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_src), src.nbytes))
 	gpu.check(lib.ogd_dev_alloc(ctypes.byref(d_map), 277 * 41 * 8))
@@ -181,25 +183,26 @@ def test_remap_dev_into_any_stride_and_alignment(gpu):
 			m[-1, -1] = [np.nan, 2]
 			gpu.check(lib.ogd_memcpy_h2d(d_map, m.ctypes.data, m.nbytes, None))
 			for interp in (ocv.INTER_LINEAR, ocv.INTER_NEAREST):
-				want = ocv.remap_u8(src, m, interp)
+				row = Wd * C
+				want = ocv.remap_u8(src, m, interp).reshape(Hd, row)
 				for extra in range(64 if interp == ocv.INTER_LINEAR else 8):
-					stride = Wd + extra
-					n = (Hd - 1) * stride + Wd
+					stride = row + extra
+					n = (Hd - 1) * stride + row
 					lead = (-d_out.value) % 64 + (0, 1, 37, 63, 4, 32)[extra % 6]
 					total = lead + n + 128
 					assert total <= cap
 					out = np.full(total, 0xEE, dtype=np.uint8)
 					gpu.check(lib.ogd_memcpy_h2d(d_out, out.ctypes.data, total, None))
-					gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, 1, W, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
+					gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, C, W * C, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
 					gpu.check(lib.ogd_memcpy_d2h(out.ctypes.data, d_out, total, None))
 					gpu.check(lib.ogd_stream_sync(None))
 					launches += 1
 					msg = "Wd %d Hd %d stride %d lead %d interp %d" % (Wd, Hd, stride, lead, interp)
 					assert (out[:lead] == 0xEE).all() and (out[lead + n:] == 0xEE).all(), msg
-					rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, Wd), strides=(stride, 1))
+					rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, row), strides=(stride, 1))
 					np.testing.assert_array_equal(rows, want, err_msg=msg)
 					if extra:
-						gaps = np.lib.stride_tricks.as_strided(out[lead + Wd:], shape=(Hd - 1, extra), strides=(stride, 1))
+						gaps = np.lib.stride_tricks.as_strided(out[lead + row:], shape=(Hd - 1, extra), strides=(stride, 1))
 						assert (gaps == 0xEE).all(), msg
 	finally:
 		for d in (d_src, d_map, d_out):
@@ -207,25 +210,28 @@ def test_remap_dev_into_any_stride_and_alignment(gpu):
 	assert launches == 7 * 72
 
 
-def test_remap_dev_random_shapes_strides_and_maps(gpu):
-	"""Eight hundred seeded random cases through ogd_remap_u8_dev (one channel: the sheared tiles) against the oracle,
-	bit for bit: source and output sizes, output strides and misalignments, both interpolations; maps that are smooth,
-	slanted, sheared beyond the LDS window, incoherent or folded with a NaN; guard bytes around and between the rows."""
+@pytest.mark.parametrize("C,cases", [(1, 800), (3, 500), (4, 300)])
+def test_remap_dev_random_shapes_strides_and_maps(gpu, C, cases):
+	"""Seeded random cases through ogd_remap_u8_dev against the oracle, bit for bit, for one, three (both: sheared
+	tiles) and four channels: source and output sizes, output strides and misalignments, both interpolations; maps that
+	are smooth, slanted, sheared beyond the LDS window, incoherent or folded with a NaN; guard bytes around and between
+	the rows."""
 	lib = gpu.load()
-	rng = np.random.default_rng(7)
-	cap_src, cap_map, cap_out = 1 << 20, 8 << 20, 2 << 20
+	rng = np.random.default_rng(7 + C)
+	cap_src, cap_map, cap_out = 4 << 20, 8 << 20, 4 << 20
 	d_src, d_map, d_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
 	for d, n in ((d_src, cap_src), (d_map, cap_map), (d_out, cap_out)):
 		gpu.check(lib.ogd_dev_alloc(ctypes.byref(d), n))
-	for case in range(800):
+	for case in range(cases):
 		H, W = int(rng.integers(1, 700)), int(rng.integers(1, 900))
 		Hd, Wd = int(rng.integers(1, 120)), int(rng.integers(1, 1100))
 		if rng.random() < 0.1:
 			Wd = int(rng.integers(1, 70))
-		stride = Wd + int(rng.choice([0, 0, 1, 5, 27, 32, 59, 64, int(rng.integers(0, 200))]))
+		row = Wd * C
+		stride = row + int(rng.choice([0, 0, 1, 5, 27, 32, 59, 64, int(rng.integers(0, 200))]))
 		lead = int(rng.integers(0, 130))
 		interp = int(rng.choice([1, 1, 1, 0]))
-		src = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+		src = rng.integers(0, 256, size=(H, W) if C == 1 else (H, W, C), dtype=np.uint8)
 		yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
 		kind = int(rng.integers(0, 5))
 		if kind == 0:
@@ -240,23 +246,23 @@ def test_remap_dev_random_shapes_strides_and_maps(gpu):
 			m = np.stack([np.abs(W / 2 - xx), np.abs(H / 2 - yy * 2)], -1)
 			m[rng.integers(0, Hd), rng.integers(0, Wd)] = [np.nan, 1e30]
 		m = np.ascontiguousarray(m.astype(np.float32))
-		n = (Hd - 1) * stride + Wd
+		n = (Hd - 1) * stride + row
 		total = lead + n + 200
 		assert src.nbytes <= cap_src and m.nbytes <= cap_map and total <= cap_out
-		want = ocv.remap_u8(src, m, interp)
+		want = ocv.remap_u8(src, m, interp).reshape(Hd, row)
 		out = np.full(total, 0xA5, dtype=np.uint8)
 		gpu.check(lib.ogd_memcpy_h2d(d_src, src.ctypes.data, src.nbytes, None))
 		gpu.check(lib.ogd_memcpy_h2d(d_map, m.ctypes.data, m.nbytes, None))
 		gpu.check(lib.ogd_memcpy_h2d(d_out, out.ctypes.data, total, None))
-		gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, 1, W, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
+		gpu.check(lib.ogd_remap_u8_dev(d_src, H, W, C, W * C, d_map, Hd, Wd, d_out.value + lead, stride, interp, None))
 		gpu.check(lib.ogd_memcpy_d2h(out.ctypes.data, d_out, total, None))
 		gpu.check(lib.ogd_stream_sync(None))
-		msg = "case %d: src %dx%d out %dx%d stride %d lead %d interp %d kind %d" % (case, W, H, Wd, Hd, stride, lead, interp, kind)
-		rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, Wd), strides=(stride, 1))
+		msg = "case %d: C %d src %dx%d out %dx%d stride %d lead %d interp %d kind %d" % (case, C, W, H, Wd, Hd, stride, lead, interp, kind)
+		rows = np.lib.stride_tricks.as_strided(out[lead:], shape=(Hd, row), strides=(stride, 1))
 		np.testing.assert_array_equal(rows, want, err_msg=msg)
 		guard = np.ones(total, dtype=bool)
 		for y in range(Hd):
-			guard[lead + y * stride: lead + y * stride + Wd] = False
+			guard[lead + y * stride: lead + y * stride + row] = False
 		assert (out[guard] == 0xA5).all(), "wrote outside its rows, " + msg
 	for d in (d_src, d_map, d_out):
 		lib.ogd_dev_free(d)

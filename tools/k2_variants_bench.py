@@ -12,6 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from origami_amd import _shim, synth  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # substring of the case names to run
 torch.cuda.set_device(0)
 _shim.init(0)
 lib, check = _shim.load(), _shim.check
@@ -33,8 +34,10 @@ def timed(fn):
 	return e0.elapsed_time(e1) / iters
 
 
-def case(name, src, cell, interp, sx=1.0, sy=1.0):
-	warp = synth.Warp(( W, H), 0.03, 0.02, 2, 1)
+def case(name, src, cell, interp, sx=1.0, sy=1.0, amp=(0.03, 0.02)):
+	if only and only not in name:
+		return
+	warp = synth.Warp(( W, H), amp[0], amp[1], 2, 1)
 	nodes = warp.node_grid(cell)
 	h, w = nodes.shape[:2]
 	Hd, Wd = h * cell, w * cell
@@ -67,5 +70,7 @@ case("gray 6000x8000, cell 25, linear", gray, 25, _shim.INTER_LINEAR)
 case("gray 6000x8000, cell 8, linear", gray, 8, _shim.INTER_LINEAR)
 case("RGB 6000x8000, cell 8, linear", rgb, 8, _shim.INTER_LINEAR)
 case("RGBA 6000x8000, cell 8, linear", np.dstack([rgb, gray]), 8, _shim.INTER_LINEAR)
+case("RGB 6000x8000, cell 25, linear", rgb, 25, _shim.INTER_LINEAR)
+case("RGB 6000x8000, cell 25, linear, heavy warp 0.12 rad", rgb, 25, _shim.INTER_LINEAR, amp=(0.12, 0.12))
 case("labels 1280x2400 -> page grid, cell 8, nearest", labels, 8, _shim.INTER_NEAREST, 1280 / W, 2400 / H)
 case("gray 6000x8000, cell 25, nearest", gray, 25, _shim.INTER_NEAREST)
