@@ -453,8 +453,25 @@ def config4_leg(torch, lib, check, dev, stream, iters=20):
 			fi.handle if fi is not None else None, fe.handle, fb.ctypes.data, 0.0, 0.0, 1.0, nx, ny, lattice.data_ptr(), 1, nx, 0, stream))
 
 	ms_k1b = _event_time(torch, k1b, max(3, iters // 4), warm=1)
-	h, w = grid.points("sample").shape[:2]
+	nodes = grid.points("sample")
+	h, w = nodes.shape[:2]
+	# the page itself through the heavy grid (a marched grid turns locally by up to 0.12 rad: taller source windows)
+	Hd, Wd = h * CELL, w * CELL
+	d_nodes = torch.from_numpy(np.ascontiguousarray(nodes)).to(dev)
+	d_page = torch.from_numpy(synth.text_page(rng, (W, H))).to(dev)
+	d_map = torch.empty((Hd, Wd, 2), dtype=torch.float32, device=dev)
+	d_out = torch.empty((Hd, Wd), dtype=torch.uint8, device=dev)
+	check(lib.ogd_grid_fill_dev(d_nodes.data_ptr(), h, w, CELL, 1.0, 1.0, d_map.data_ptr(), stream))
+	ms_k2 = _event_time(torch, lambda: check(lib.ogd_remap_u8_dev(
+		d_page.data_ptr(), H, W, 1, W, d_map.data_ptr(), Hd, Wd, d_out.data_ptr(), Wd, 1, stream)), iters)
+	ref = d_out.clone()
+	ms_fused = _event_time(torch, lambda: check(lib.ogd_dewarp_u8_dev(
+		d_page.data_ptr(), H, W, 1, W, d_nodes.data_ptr(), h, w, CELL, 1.0, 1.0, d_out.data_ptr(), Wd, 1, stream)), iters)
+	if not torch.equal(ref, d_out):
+		raise SystemExit("bench: fused path differs from K1a + K2 on the heavily warped page")
 	return {
+		"k2_gray_heavy": _kernel_entry(ms_k2, Hd * Wd * 9 + H * W, "ogd_remap_u8_dev, gray page through the heavily warped marched grid (10 B/px)"),
+		"fused_gray_heavy": _kernel_entry(ms_fused, Hd * Wd + H * W + h * w * 8, "ogd_dewarp_u8_dev, same page and grid (~2 B/px; VALU-bound)"),
 		"what": "configs[4]: heavily warped 6000x8000 page (A = B = 0.12 rad), 2000 h + 3000 v flow samples, 5000 contour rings (%d points), node grid %dx%d" % (len(flat), w, h),
 		"grid_create_ms": round(t_grid * 1e3, 2),
 		"transformer_build_ms": round(t_tf * 1e3, 2),

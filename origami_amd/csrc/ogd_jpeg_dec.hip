@@ -413,14 +413,24 @@ walk:
   }
   // One atomic per walk, AFTER the loop.  With `atomicAdd(rst_check, 1)` inside the divergent loop above, the round-1
   // form of this kernel (commit 465d566) decoded long three-component streams to wrong pixels, differently on
-  // every run.  Round 2 reproduced it on demand and narrowed it down (tools/jpeg_atomic_variants.py,
-  // profiles/r02/c_jpeg_atomic_probe.log): it is NOT the compiler's atomic optimiser (same fault with
-  // -amdgpu-atomic-optimizer-strategy=None); a plain store in the atomic's place is harmless; the atomic WITH its
-  // return value used, or followed by s_waitcnt 0, is harmless too.  What faults is a no-return global atomic left
-  // in flight while the wave goes on to its next loads and sub-dword coefficient stores (every wait the compiler
-  // placed in that loop is a full vmcnt(0), operands and EXEC handling around the atomic check out in the ISA) —
-  // and only in that code shape: today's loop with the same atomic put back passes.  Rule kept in this library:
-  // no fire-and-forget atomic inside a walk; count in a register, publish once at the end.
+  // every run.  Round 2 reproduced it on demand (tools/jpeg_atomic_variants.py, profiles/r02/c_jpeg_atomic_probe.log):
+  // not the compiler's atomic optimiser; a plain store in the atomic's place, the atomic with its return value used,
+  // or followed by s_waitcnt 0, are all harmless.  Round 3 settled what it is NOT (tools/jpeg_atomic_owner_probe.py,
+  // profiles/r03/i_jpeg_owner_probe.log: the faulty pass and a clean copy of the kernel run back to back on the same
+  // settled chunk states and are compared coefficient by coefficient): it is not a race of this protocol.  Of 9.6 M /
+  // 72 M coefficients 36 000 / 3 000 differ, and EVERY one of them is a non-zero value at a position where the clean
+  // pass also stored a non-zero value — no store is missing, none lands where the clean pass wrote nothing, every
+  // restart is counted: the parse (code lengths, runs, block and interval borders, hence every address) is right in
+  // every walk, only the magnitude bits stored are wrong; a second walk on a coefficient's slot would have to be on
+  // another parse and would leave foreign and missing stores.  The damaged coefficients are those of the workgroups
+  // with index >= 256 (chunks >= 65536: 195-202 of the 211 such wavefronts of one file, all 16 of another, ~60 of 64
+  // lanes each; a file of 767 wavefronts, every one of which executes the atomic, decodes right), whether or not any
+  // lane of the wavefront ever took a restart — five of six damaged wavefronts never execute the atomic at all.  And
+  // only in that exact code shape: the same kernel with a template flag around the atomic and one store after the
+  // loop shows no difference in 86 M coefficients.  Address-right, value-wrong stores in wavefronts that never reach
+  // the atomic, selected by their workgroup index, in one instruction schedule only: below the source level (code
+  // generation or hardware; not resolved further).  Rule kept in this library: no fire-and-forget atomic inside a
+  // walk; count in a register, publish once at the end; tests/test_gpu_jpeg_decode.py keeps the case.
   if (WRITE && RST) {
     if (taken) atomicAdd(rst_check, taken);
     if (misplaced) rst_check[1] = 1;

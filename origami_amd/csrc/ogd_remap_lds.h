@@ -325,8 +325,16 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   constexpr int RW = 64 / LX;   // output rows per wave pass
   constexpr int TH = RW * RPT;  // tile height
   constexpr int TW = 4 * LX;    // tile width
-  // LDS pitch (bytes): a multiple of 4, of 8 for three / four channels (their windows are staged in 8-byte pieces)
-  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * 5) / 4 + (TAPS + 6) * C + (C == 1 ? 3 : 7)) & (C == 1 ? ~3 : ~7);
+  // LDS pitch of the source window (bytes; a multiple of 4, of 8 for three / four channels, whose windows are staged
+  // in 8-byte pieces): tile width x stretch + taps and alignment.  Stretch 5/4 for K2 proper; 3/2 for the 32-pixel
+  // tiles of the fused kernel with one and three channels, whose slices have rows to spare — the pitch itself costs
+  // nothing (48, 52, 60 bytes: 64.2, 63.7, 64.3 us, profiles/r03/h_pitch.log: LDS bank conflicts are not what
+  // holds this kernel), and a page whose map stretches by more than the pitch allows sends the tile down the slow
+  // path (18 % of the tiles of configs[4]'s heavily warped page at 5/4, tools/heavy_tiles.py).
+#ifndef RL_PF_NUM
+#define RL_PF_NUM ((!MapSrc::SHEAR && C != 4) ? 6 : 5)
+#endif
+  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * RL_PF_NUM) / 4 + (TAPS + 6) * C + (C == 1 ? 3 : 7)) & (C == 1 ? ~3 : ~7);
   constexpr int MAXROWS = LDSW / PF;
   // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
   constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
