@@ -80,6 +80,8 @@ def parse_args():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="skip the host-ring pipeline leg (configs[2])")
 	ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[3] / configs[4] kernel legs and the batch-CLI stage leg")
+	ap.add_argument("--no-stage-leg", action="store_true",
+		help="skip the batch-CLI stage leg only (it starts child processes: leave it out under rocprofv3, whose preloaded tool would ride along into them)")
 	ap.add_argument("--pipeline-jobs", type=int, default=0, help="page jobs per GPU in the pipeline leg (0 = 2 x pages)")
 	ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
 	ap.add_argument("--harness-selftest", action="store_true",
@@ -755,10 +757,11 @@ def main():
 						line[key] = leg(torch, lib, check, dev, stream)
 					except Exception as e:  # noqa: BLE001
 						line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-			try:
-				line["stage"] = stage_leg(world, workers=(1, 8) if world == 1 else (4,))
-			except Exception as e:  # noqa: BLE001
-				line["stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
+			if not args.no_stage_leg:
+				try:
+					line["stage"] = stage_leg(world, workers=(1, 8) if world == 1 else (4,))
+				except Exception as e:  # noqa: BLE001
+					line["stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
 		print(json.dumps(line), flush=True)
 	if world > 1:
 		dist.barrier()

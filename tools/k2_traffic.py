@@ -17,7 +17,9 @@ W, H, CELL = 6000, 8000, 25
 
 def per_launch(d, counter):
 	vals = {}
-	for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+	# gpurun merges every call's files into the same local directory: take the newest pass only (dispatch ids repeat)
+	files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=lambda f: Path(f).stat().st_mtime)
+	for f in files[-1:]:
 		for row in csv.DictReader(open(f)):
 			if "MapGlobal" in row["Kernel_Name"] and "<1, 1, 16, 2, 4096" in row["Kernel_Name"] and row["Counter_Name"] == counter:
 				vals.setdefault(row["Dispatch_Id"], 0.0)
