@@ -357,6 +357,11 @@ class Processor:
 			return
 
 		devices = self.worker_devices(n_workers)
+		if n_workers > len(set(devices)):
+			# several workers per GPU share a few cores each: their threads sleep while they wait for the device instead of
+			# spinning (HIP's default) on cores the other workers' host work needs (7.5 -> 6.9 ms/page at 8 workers,
+			# profiles/r03/m_sync_mode.log); the spawned workers inherit the setting
+			os.environ.setdefault("OGD_SYNC", "block")
 		# small enough chunks that every worker gets several pulls (dynamic load balance)
 		chunk_size = max(1, min(self._lock_chunk_size, -(-len(queued) // (4 * n_workers))))
 		ctx = multiprocessing.get_context("spawn")

@@ -41,6 +41,16 @@ static int bind_device(int device) {
     if (hipGetDevice(&device) != hipSuccess) device = 0;
   }
   if (device >= n) return fail(OGD_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  // How a host thread waits for the device.  HIP's default spins; a stage worker waits for milliseconds at a time
+  // (the march's walks are latency-bound launches), and with several workers per GPU on a box with two cores per
+  // worker the spinning threads take the cores the other workers' host work needs.  OGD_SYNC = spin | yield | block
+  // (hipDeviceSchedule*); must be set before the device's context exists, so the first binding thread decides.
+  if (const char* mode = getenv("OGD_SYNC")) {
+    const unsigned flags = !strcmp(mode, "block") ? hipDeviceScheduleBlockingSync
+                           : !strcmp(mode, "yield") ? hipDeviceScheduleYield
+                           : !strcmp(mode, "spin") ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+    if (hipSetDeviceFlags(flags) != hipSuccess) (void)hipGetLastError();  // context exists already: keep its mode
+  }
   OGD_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   OGD_HIP(hipGetDeviceProperties(&prop, device));
