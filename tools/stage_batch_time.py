@@ -60,9 +60,14 @@ def main():
 		print("second pass: %.3f s = %.1f ms/page = %.0f MP/s (page megapixels per second through the stage)" % (
 			dt, 1e3 * dt / n_pages, mp / dt))
 		if len(worker_counts) > 1:
+			import resource
 			for n in worker_counts[1:]:
+				r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
 				dt = run(True, n)
-				print("%2d workers : %.3f s = %.1f ms/page = %.0f MP/s" % (n, dt, 1e3 * dt / n_pages, mp / dt), flush=True)
+				r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+				cpu = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
+				print("%2d workers : %.3f s = %.1f ms/page = %.0f MP/s; workers' CPU time %.1f s = %.1f core-ms/page (user %.1f s, system %.1f s), %.1f cores busy" % (
+					n, dt, 1e3 * dt / n_pages, mp / dt, cpu, 1e3 * cpu / n_pages, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime, cpu / dt), flush=True)
 			return
 		# the stage that writes annotation.dewarped.jpg from dewarp.zip (ref: origami/batch/utils/dewarp.py)
 		from origami_amd.batch.utils.dewarp import dewarp as dewarp_image_stage
