@@ -22,6 +22,20 @@
 #include "ogd_remap_math.h"
 #include "ogd_resize_math.h"
 
+// Round-3 switches (each measured on its own; tools/build_variant.sh builds the other settings)
+#ifndef RL_STAGE_SCALAR
+#define RL_STAGE_SCALAR 1  // window staging: wave-uniform row addresses on the scalar unit
+#endif
+#ifndef RL_PK_QUANT
+#define RL_PK_QUANT 1  // x and y of a pixel quantised by one v_pk_fma_f32
+#endif
+#ifndef RL_STAGE_QW_ALL
+#define RL_STAGE_QW_ALL 1  // 8-byte window pieces for every kernel (0: only K2 proper with three / four channels)
+#endif
+#ifndef RL_WHOLE_TILE
+#define RL_WHOLE_TILE 1  // tiles that lie inside the output store without per-row tests
+#endif
+
 namespace ogd {
 
 typedef float rl_f4 __attribute__((ext_vector_type(4), aligned(8)));
@@ -40,6 +54,9 @@ typedef short rl_s2 __attribute__((ext_vector_type(2)));
 typedef const float RL_GLOBAL* rl_gf;
 typedef const rl_f4 RL_GLOBAL* rl_gf4;
 typedef const float2 RL_GLOBAL* rl_gf2;
+typedef const uint8_t RL_GLOBAL* rl_gu8;
+typedef const rl_u32u RL_GLOBAL* rl_gu32u;
+typedef const rl_u64u RL_GLOBAL* rl_gu64u;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const uint32_t __attribute__((address_space(3)))* rl_lds_u32;
 #else
@@ -274,7 +291,27 @@ __device__ __forceinline__ int rl_shear(int sh0, int step, int wrap, int rr) {
   return sh0 + (wrap ? ((d + 32) & 63) - 32 : d);
 }
 
-// Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).
+// First window row of a staging pass: `row` clamped to [0, last] — on wave-uniform values, i.e. on the scalar unit.
+__device__ __forceinline__ int rl_stage_row(int row, int last) {
+  return __builtin_amdgcn_readfirstlane(max(min(row, last), 0));
+}
+
+// A wave-uniform value pinned to scalar registers and cut off from what it was computed from — otherwise the compiler
+// folds a scalar row offset back into 64-bit vector multiply-adds per load.
+template <class T>
+__device__ __forceinline__ T rl_scalar(T v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// Wavefronts per workgroup (neighbouring tiles of one tile row): 4; tools/kbench builds other values to measure
+#ifndef RL_WPB
+#define RL_WPB 4
+#endif
+
+// Slow path of one tile: every pixel straight from global memory (same bytes as the LDS path).  Kept as small as
+// it is on purpose: called as the last thing the kernel does, with nothing live across the call, and with few enough
+// registers of its own that neither side needs scratch memory.
 template <int C, int INTERP, int LX, int RPT, class MapSrc>
 __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, int H, int W,
                                                ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
@@ -310,41 +347,49 @@ __device__ __noinline__ void remap_tile_global(const uint8_t* __restrict__ src, 
 #define RL_WMC 5
 #endif
 #define RL_WAVES_PER_SIMD(C, RPT) ((C) == 1 ? ((RPT) <= 2 ? 8 : RL_W1B) : RL_WMC)
-// Wavefronts per workgroup (neighbouring tiles of one tile row): 4; tools/kbench builds other values to measure
-#ifndef RL_WPB
-#define RL_WPB 4
-#endif
+// LDS geometry of a kernel instance
 template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
-__global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
-    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
-    uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb, int sh_step = 0, int sh_wrap = 0, int sh_bias = 0) {
+struct RlGeom {
+  static constexpr bool SHEAR = MapSrc::SHEAR && rl_shear_channels(C);
+  static constexpr int TAPS = INTERP == OGD_INTER_LINEAR ? 2 : 1;
+  static constexpr int TW = 4 * LX;
+  // LDS pitch of the source window (bytes, a multiple of 8: windows are staged in 8-byte pieces): tile width x
+  // stretch + taps and alignment.  Stretch 5/4 for K2 proper; 3/2 for the 32-pixel tiles of the fused kernel with
+  // one and three channels, whose slices have rows to spare — the pitch itself costs nothing (48, 52, 60 bytes:
+  // 64.2, 63.7, 64.3 us, profiles/r03/h_pitch.log: LDS bank conflicts are not what holds this kernel), and a page
+  // whose map stretches by more than the pitch allows sends the tile down the slow path (18 % of the tiles of
+  // configs[4]'s heavily warped page at 5/4, tools/heavy_tiles.py).
+#ifndef RL_PF_NUM
+#define RL_PF_NUM ((!MapSrc::SHEAR && C != 4) ? 6 : 5)
+#endif
+  static constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * RL_PF_NUM) / 4 + (TAPS + 6) * C + 7) & ~7;
+  static constexpr int MAXROWS = LDSW / PF;
+  // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
+  static constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
+};
+
+// Page-size bounds as floats.
+struct RlBounds {
+  float xmax, ymax;  // W - 1, H - 1
+  float qxhi, qyhi;  // upper clamp bounds of the quantised coordinates: MAGIC + QS * W, MAGIC + QS * H
+};
+constexpr float RL_MAGIC = 12582912.f;  // 1.5 * 2^23; bit pattern 0x4B400000, a multiple of 32
+
+// One tile (t) by one wavefront; `win` is the wavefront's LDS slice.  A tile that does not fit the LDS path goes to
+// remap_tile_global before anything is written.
+template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
+__device__ __forceinline__ void rl_tile(const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc& ms,
+                                        int Hd, int Wd, uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int sh_step,
+                                        int sh_wrap, int sh_bias, uint32_t* win, int t, int lane, const RlBounds bd) {
+  typedef RlGeom<C, INTERP, LX, RPT, LDSW, MapSrc> G;
   constexpr bool LIN = INTERP == OGD_INTER_LINEAR;
-  constexpr bool SHEAR = MapSrc::SHEAR && rl_shear_channels(C);
-  constexpr int TAPS = LIN ? 2 : 1;
+  constexpr bool SHEAR = G::SHEAR;
+  constexpr int TAPS = G::TAPS;
   constexpr int SHIFT = LIN ? 5 : 0;
   constexpr int RW = 64 / LX;   // output rows per wave pass
   constexpr int TH = RW * RPT;  // tile height
   constexpr int TW = 4 * LX;    // tile width
-  // LDS pitch of the source window (bytes; a multiple of 4, of 8 for three / four channels, whose windows are staged
-  // in 8-byte pieces): tile width x stretch + taps and alignment.  Stretch 5/4 for K2 proper; 3/2 for the 32-pixel
-  // tiles of the fused kernel with one and three channels, whose slices have rows to spare — the pitch itself costs
-  // nothing (48, 52, 60 bytes: 64.2, 63.7, 64.3 us, profiles/r03/h_pitch.log: LDS bank conflicts are not what
-  // holds this kernel), and a page whose map stretches by more than the pitch allows sends the tile down the slow
-  // path (18 % of the tiles of configs[4]'s heavily warped page at 5/4, tools/heavy_tiles.py).
-#ifndef RL_PF_NUM
-#define RL_PF_NUM ((!MapSrc::SHEAR && C != 4) ? 6 : 5)
-#endif
-  constexpr int PF = (((TW + (SHEAR ? 64 : 0)) * C * RL_PF_NUM) / 4 + (TAPS + 6) * C + (C == 1 ? 3 : 7)) & (C == 1 ? ~3 : ~7);
-  constexpr int MAXROWS = LDSW / PF;
-  // + 3 dwords of slack (tap gathers read up to 2 dwords past a row), rounded to 16 bytes (b128 accesses in MapNodes)
-  constexpr int WIN_DW = ((PF / 4) * MAXROWS + 3 + 3) & ~3;
-
-  __shared__ __attribute__((aligned(16))) uint32_t win_all[RL_WPB * WIN_DW];
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int t = blockIdx.x * RL_WPB + wave;
-  if (t >= nb) return;  // wave-uniform
-  uint32_t* win = win_all + wave * WIN_DW;
+  constexpr int PF = G::PF, MAXROWS = G::MAXROWS, WIN_DW = G::WIN_DW;
   const int lx4 = (lane % LX) * 4, ly = lane / LX;
   const int by = t / nbx, bx = t - by * nbx;
   const int X = bx * TW + lx4;
@@ -366,7 +411,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   }
   float mv[RPT][8];
   bool interior;  // wave-uniform: the clamp below cannot change any map value of this tile
-  if (!ms.template load<LX, RPT>(X, Xr, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH, (float)(W - 1), (float)(H - 1),
+  if (!ms.template load<LX, RPT>(X, Xr, Yb, mv, win, WIN_DW, lane, bx * TW, by * TH, bd.xmax, bd.ymax,
                                  interior)) {  // wave-uniform
     remap_tile_global<C, INTERP, LX, RPT>(src, H, W, ss, ms, Hd, Wd, dst, ds, X, Yb, sh0, sh_step, sh_wrap);
     return;
@@ -377,28 +422,45 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   // integer, ties to even, in the adder (that is cvRound), and leaves it in the low mantissa bits.  The
   // product m * 32 is exact, so one fma gives cvRound(m * 32); the clamp (applied to m: the bounds are
   // multiples of 32) keeps the sum inside [2^23, 2^24) and sends NaN / huge values to the border.
-  const float xlo = LIN ? -2.f : -1.f, xhi = (float)W;
-  const float ylo = xlo, yhi = (float)H;
-  constexpr float MAGIC = 12582912.f;  // 1.5 * 2^23; bit pattern 0x4B400000, a multiple of 32
+  const float xlo = LIN ? -2.f : -1.f, ylo = xlo;  // the upper bounds are W and H (bd)
+  constexpr float MAGIC = RL_MAGIC;
   int lp[RPT][4];
   uint32_t wa[RPT][4], wb[RPT][4];
   int mn = 0x7fff7fff, mx = (int)0x80008000;
-  if (!interior) {
+  // x and y of a pixel are quantised by one packed instruction (v_pk_fma_f32 / v_pk_add_f32: each half rounded as the
+  // scalar form).  The clamp comes after it, on the sums: rounding is monotone and the bounds are integers, so
+  // med3(fma(m, 32, MAGIC), MAGIC + 32 lo, MAGIC + 32 hi) == fma(med3(m, lo, hi), 32, MAGIC) for every m, huge
+  // values and NaN (which med3 sends to its lower bound either way) included.
+  constexpr float QS = LIN ? 32.f : 1.f;
+  const float qxlo = MAGIC + QS * xlo, qxhi = bd.qxhi, qylo = MAGIC + QS * ylo, qyhi = bd.qyhi;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const f32x2 cxy = {mv[r][k], mv[r][k + 1]}, magic2 = {MAGIC, MAGIC}, k32 = {32.f, 32.f};
+      f32x2 qf = LIN ? __builtin_elementwise_fma(cxy, k32, magic2) : cxy + magic2;
+      if (!RL_PK_QUANT) {
+        qf.x = LIN ? __builtin_fmaf(cxy.x, 32.f, MAGIC) : __fadd_rn(cxy.x, MAGIC);
+        qf.y = LIN ? __builtin_fmaf(cxy.y, 32.f, MAGIC) : __fadd_rn(cxy.y, MAGIC);
+        asm volatile("" : "+v"(qf.x), "+v"(qf.y));
+      }
+      mv[r][k] = qf.x;
+      mv[r][k + 1] = qf.y;
+    }
+  if (__builtin_expect(!interior, 0)) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
-        mv[r][k] = __builtin_amdgcn_fmed3f(mv[r][k], xlo, xhi);
-        mv[r][k + 1] = __builtin_amdgcn_fmed3f(mv[r][k + 1], ylo, yhi);
+        mv[r][k] = __builtin_amdgcn_fmed3f(mv[r][k], qxlo, qxhi);
+        mv[r][k + 1] = __builtin_amdgcn_fmed3f(mv[r][k + 1], qylo, qyhi);
       }
   }
 #pragma unroll
   for (int r = 0; r < RPT; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float cxf = mv[r][2 * k], cyf = mv[r][2 * k + 1];
-      const uint32_t qbx = __float_as_uint(LIN ? __builtin_fmaf(cxf, 32.f, MAGIC) : __fadd_rn(cxf, MAGIC));
-      const uint32_t qby = __float_as_uint(LIN ? __builtin_fmaf(cyf, 32.f, MAGIC) : __fadd_rn(cyf, MAGIC));
+      const uint32_t qbx = __float_as_uint(mv[r][2 * k]), qby = __float_as_uint(mv[r][2 * k + 1]);
       const int cx = __builtin_amdgcn_sbfe((int)qbx, SHIFT, 16), cy = __builtin_amdgcn_sbfe((int)qby, SHIFT, 16);
       lp[r][k] = __mul24(cy, PF) + (C == 1 ? cx : __mul24(cx, C));
       if (LIN) {
@@ -433,6 +495,12 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
 #ifndef RL_STAGE_QW
 #define RL_STAGE_QW 1
 #endif
+#ifndef RL_STAGE_UQ1_K2
+#define RL_STAGE_UQ1_K2 6
+#endif
+#ifndef RL_STAGE_UQ1_FUSED
+#define RL_STAGE_UQ1_FUSED 5
+#endif
 #ifndef RL_STAGE_UQ
 #define RL_STAGE_UQ 8  // 8-byte pieces in flight per lane
 #endif
@@ -444,41 +512,78 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
     constexpr int U = C == 1 ? RL_STAGE_U : RL_STAGE_U_MC;
     const uint8_t* pw = src + ((ptrdiff_t)mny * ss + x0b);  // wave-uniform base + 32-bit lane offsets
     const uint32_t ss32 = (uint32_t)ss;                      // the window lies inside the image: ss > 0
-    if (RL_STAGE_QW && MapSrc::STAGE_QW && C > 1 && x0b + 8 * ((wbytes + 7) >> 3) <= WB) {  // wave-uniform
+    const rl_gu8 pwg = (rl_gu8)pw;
+    if (RL_STAGE_QW && (RL_STAGE_QW_ALL || (MapSrc::STAGE_QW && C > 1)) && x0b + 8 * ((wbytes + 7) >> 3) <= WB) {  // wave-uniform
       // three / four channels: window rows of 50-70 dwords are staged as 8-byte pieces — half the loads and LDS
       // writes, and 26-35 pieces per row let the wavefront take two rows per pass (PF is a multiple of 8 and the
       // slice 16-byte aligned; global loads need no more than their dword alignment)
-      static_assert(C == 1 || PF % 8 == 0, "8-byte window pieces need an 8-byte pitch");
+      static_assert(PF % 8 == 0, "8-byte window pieces need an 8-byte pitch");
+      // pieces in flight per lane: what the window of a tile needs in one trip (one channel: 8 columns x 8 rows per
+      // pass and ~35 rows for the fused kernel's 32 x 32 tiles, 32 x 2 and ~12 rows for K2's 64 x 8) and no more — the
+      // tap addresses and weights of all the lane's pixels are live here, and 8 pieces spilled
+      constexpr int UQ = C == 1 ? (MapSrc::SHEAR ? RL_STAGE_UQ1_K2 : RL_STAGE_UQ1_FUSED) : RL_STAGE_UQ;
       const int P8 = (wbytes + 7) >> 3;
-      const int sh = P8 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
-      const int r0 = lane >> sh;
-      uint64_t* win8 = reinterpret_cast<uint64_t*>(win);
+      const int sh = P8 <= 8 ? 3 : P8 <= 16 ? 4 : P8 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
+      const int r0 = min(lane >> sh, nrows - 1);
+      uint64_t* win8 = reinterpret_cast<uint64_t*>(win) + __mul24(r0, PF / 8);
+      const uint32_t goff = __umul24((uint32_t)r0, ss32);
       for (int c = lane & (cw - 1); c < P8; c += cw) {
-        for (int rb = 0; rb < nrows; rb += RL_STAGE_UQ * rp) {  // wave-uniform trip count
-          uint64_t v[RL_STAGE_UQ];
+        for (int rb = 0; rb < nrows; rb += UQ * rp) {  // wave-uniform trip count
+          uint64_t v[UQ];
+          uint32_t lo = goff + 8u * (uint32_t)c;
 #pragma unroll
-          for (int u = 0; u < RL_STAGE_UQ; ++u) {
-            const uint32_t row = (uint32_t)min(rb + r0 + u * rp, nrows - 1);
-            v[u] = *reinterpret_cast<const rl_u64u*>(pw + (__umul24(row, ss32) + 8u * (uint32_t)c));
+          for (int u = 0; u < UQ; ++u) {
+            if (u && rb + u * rp >= nrows) continue;  // wave-uniform: a pass that begins past the window is skipped
+            const int row = rl_stage_row(rb + u * rp, nrows - rp);  // wave-uniform: the row's address is scalar arithmetic
+            asm volatile("" : "+v"(lo));  // (in this block, so that the load is scalar base + zero-extended lane offset)
+            v[u] = *(rl_gu64u)(rl_scalar(pwg + (uint32_t)row * ss32) + lo);  // row * ss < 2^31
           }
 #pragma unroll
-          for (int u = 0; u < RL_STAGE_UQ; ++u) {
-            const int row = min(rb + r0 + u * rp, nrows - 1);
-            win8[__mul24(row, PF / 8) + c] = v[u];
+          for (int u = 0; u < UQ; ++u) {
+            if (u && rb + u * rp >= nrows) continue;
+            const int row = rl_stage_row(rb + u * rp, nrows - rp);
+            win8[rl_scalar(row * (PF / 8)) + c] = v[u];
           }
         }
       }
     } else {
     const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
-    const int r0 = lane >> sh;
+    // Row u of a pass is rows (row_u, row_u + 1) of the window for the two half-waves (or one row for all lanes):
+    // row_u is wave-uniform, so the source address of a load is a scalar base + one per-lane offset computed once,
+    // and the LDS address one vector addition (it was add + min + two multiply-adds per load: a sixth of the fused
+    // kernel's vector instructions).  Passes that reach past the window re-read and re-write its last rows.
+#if RL_STAGE_SCALAR
+    const int r0 = min(lane >> sh, nrows - 1);
+    uint32_t* const wlane = win + __mul24(r0, PF / 4);
+    const uint32_t goff = __umul24((uint32_t)r0, ss32);  // ss < 2^24
     for (int c = lane & (cw - 1); c < P4; c += cw) {
       for (int rb = 0; rb < nrows; rb += U * rp) {  // wave-uniform trip count
-        // rows past the window re-read and re-write its last row (same bytes): no predication
+        uint32_t v[U];
+        uint32_t lo = goff + 4u * (uint32_t)c;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (u && rb + u * rp >= nrows) continue;  // wave-uniform: a pass that begins past the window is skipped
+          const int row = rl_stage_row(rb + u * rp, nrows - rp);
+          asm volatile("" : "+v"(lo));
+          v[u] = *(rl_gu32u)(rl_scalar(pwg + (uint32_t)row * ss32) + lo);  // row * ss < 2^31
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (u && rb + u * rp >= nrows) continue;
+          const int row = rl_stage_row(rb + u * rp, nrows - rp);
+          wlane[rl_scalar(row * (PF / 4)) + c] = v[u];
+        }
+      }
+    }
+#else
+    const int r0 = lane >> sh;
+    for (int c = lane & (cw - 1); c < P4; c += cw) {
+      for (int rb = 0; rb < nrows; rb += U * rp) {
         uint32_t v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t row = (uint32_t)min(rb + r0 + u * rp, nrows - 1);
-          v[u] = *reinterpret_cast<const rl_u32u*>(pw + (__umul24(row, ss32) + 4u * (uint32_t)c));  // ss < 2^24
+          v[u] = *reinterpret_cast<const rl_u32u*>(pw + (__umul24(row, ss32) + 4u * (uint32_t)c));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -487,6 +592,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
         }
       }
     }
+#endif
     }
   } else {
     const int sh = P4 <= 32 ? 5 : 6, cw = 1 << sh, rp = 64 >> sh;
@@ -522,6 +628,7 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
   uint8_t* const dtile = dst + ((ptrdiff_t)(by * TH) * ds + (ptrdiff_t)(bx * TW) * C);
   const uint32_t ds32 = (uint32_t)ds;
   const uint32_t dlane = __umul24((uint32_t)ly, ds32) + (uint32_t)(lx4 * C);
+  const bool whole_tile = by * TH + TH <= Hd && bx * TW + TW <= Wd && ds > 0;  // wave-uniform
   // 4. gather + blend + store
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
@@ -577,7 +684,15 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
       }
     }
     const int Xs = Xr[r];
-    if (Y < Hd && Xs < Wd && Xs + 4 > 0) {
+    if (!SHEAR && RL_WHOLE_TILE && whole_tile) {  // wave-uniform: no per-row tests, the row's address is a scalar base + the lane's offset
+      uint8_t* d = dtile + (ptrdiff_t)(r * RW) * ds + dlane;
+#pragma unroll
+      for (int j = 0; j < 4 * C; j += 4) {
+        const uint32_t lo = __builtin_amdgcn_perm(o[j + 1], o[j], 0x0c0c0602u);
+        const uint32_t hi = __builtin_amdgcn_perm(o[j + 3], o[j + 2], 0x06020c0cu);
+        *reinterpret_cast<rl_u32u*>(d + j) = lo | hi;
+      }
+    } else if (Y < Hd && Xs < Wd && Xs + 4 > 0) {
       uint8_t* d = dtile + (int)(dlane + (uint32_t)(r * RW) * ds32 + (uint32_t)((Xs - X) * C));
       if (Xs >= 0 && Xs + 4 <= Wd) {
 #pragma unroll
@@ -593,6 +708,25 @@ __global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_
       }
     }
   }
+}
+
+// One tile per wavefront.  Several tiles per wavefront (a loop here, workgroups of 4 x tpw consecutive tiles) were
+// measured in round 3 because the counters show the fused kernel's wave slots a third empty: 2 / 4 / 8 tiles per
+// wavefront ran the fused kernel in 70.7 / 76.5 / 87 us against 68.6, and the loop alone (its loop-carried scalars
+// spill to VGPR lanes) cost K2 proper 10 % (profiles/r03/p_switches3.log).
+template <int C, int INTERP, int LX, int RPT, int LDSW, class MapSrc>
+__global__ __launch_bounds__(64 * RL_WPB, RL_WAVES_PER_SIMD(C, RPT)) void remap_u8_wave_kernel(
+    const uint8_t* __restrict__ src, int H, int W, ptrdiff_t ss, const MapSrc ms, int Hd, int Wd,
+    uint8_t* __restrict__ dst, ptrdiff_t ds, int nbx, int nb, int sh_step = 0, int sh_wrap = 0, int sh_bias = 0) {
+  constexpr int WIN_DW = RlGeom<C, INTERP, LX, RPT, LDSW, MapSrc>::WIN_DW;
+  __shared__ __attribute__((aligned(16))) uint32_t win_all[RL_WPB * WIN_DW];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int t = blockIdx.x * RL_WPB + wave;
+  if (t >= nb) return;  // wave-uniform
+  constexpr float QS = INTERP == OGD_INTER_LINEAR ? 32.f : 1.f;
+  const RlBounds bd = {(float)(W - 1), (float)(H - 1), RL_MAGIC + QS * (float)W, RL_MAGIC + QS * (float)H};
+  rl_tile<C, INTERP, LX, RPT, LDSW, MapSrc>(src, H, W, ss, ms, Hd, Wd, dst, ds, nbx, sh_step, sh_wrap, sh_bias,
+                                            win_all + wave * WIN_DW, t, lane, bd);
 }
 
 }  // namespace ogd
