@@ -361,6 +361,8 @@ class Processor:
 			# several workers per GPU share a few cores each: their threads sleep while they wait for the device instead of
 			# spinning (HIP's default) on cores the other workers' host work needs (7.5 -> 6.9 ms/page at 8 workers,
 			# profiles/r03/m_sync_mode.log); the spawned workers inherit the setting
+			# (set for the children only: this process keeps the waiting mode it started with)
+			sync_was_unset = "OGD_SYNC" not in os.environ
 			os.environ.setdefault("OGD_SYNC", "block")
 		# small enough chunks that every worker gets several pulls (dynamic load balance)
 		chunk_size = max(1, min(self._lock_chunk_size, -(-len(queued) // (4 * n_workers))))
@@ -378,6 +380,8 @@ class Processor:
 			for r in range(n_workers)]
 		for w in workers:
 			w.start()
+		if n_workers > len(set(devices)) and sync_was_unset:
+			del os.environ["OGD_SYNC"]
 		alive, done, last = n_workers, 0, time.monotonic()
 		failed = False
 		while alive > 0:

@@ -3,6 +3,7 @@
 // origami's Pool forks its workers (ref: origami/batch/core/processor.py:483).
 #include "ogd_common.h"
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,12 +46,18 @@ static int bind_device(int device) {
   // (the march's walks are latency-bound launches), and with several workers per GPU on a box with two cores per
   // worker the spinning threads take the cores the other workers' host work needs.  OGD_SYNC = spin | yield | block
   // (hipDeviceSchedule*); must be set before the device's context exists, so the first binding thread decides.
-  if (const char* mode = getenv("OGD_SYNC")) {
-    const unsigned flags = !strcmp(mode, "block") ? hipDeviceScheduleBlockingSync
-                           : !strcmp(mode, "yield") ? hipDeviceScheduleYield
-                           : !strcmp(mode, "spin") ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
-    if (hipSetDeviceFlags(flags) != hipSuccess) (void)hipGetLastError();  // context exists already: keep its mode
-  }
+  // Read ONCE per process, by the first thread that binds: HIP accepts hipSetDeviceFlags on a device whose context is
+  // in use, and a process whose waiting mode was switched under way (a later thread binding after the variable had
+  // been set for child processes) hung in hipFree (tests/test_gpu_stage.py, round 3).
+  static std::once_flag sync_once;
+  std::call_once(sync_once, [] {
+    if (const char* mode = getenv("OGD_SYNC")) {
+      const unsigned flags = !strcmp(mode, "block") ? hipDeviceScheduleBlockingSync
+                             : !strcmp(mode, "yield") ? hipDeviceScheduleYield
+                             : !strcmp(mode, "spin") ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+      if (hipSetDeviceFlags(flags) != hipSuccess) (void)hipGetLastError();  // context exists already: keep its mode
+    }
+  });
   OGD_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   OGD_HIP(hipGetDeviceProperties(&prop, device));
