@@ -248,6 +248,12 @@ int ogd_page_destroy(ogd_page* page);
 /* Dewarper.dewarped / dewarp_image of a resident page (fused K1a + K2), ref: dewarp.py:608-627. */
 int ogd_page_dewarp_u8(const ogd_page* page, const float* nodes, int h, int w, int s, float sx, float sy,
                        uint8_t* dst, ptrdiff_t dst_stride, int interp);
+/* The JPEG file of the dewarped page (ogd_dewarp_jpeg_gray) from a resident gray page: what `utils.dewarp` writes
+ * (ref: origami/batch/utils/dewarp.py:27-28) when the page is already on the device because an earlier stage of
+ * the same process put it there (ref: origami/batch/core/io.py:275-280, where every stage opens and remaps the page
+ * again).  out / cap / out_size as ogd_jpeg_encode_gray. */
+int ogd_page_dewarp_jpeg_gray(const ogd_page* page, const float* nodes, int h, int w, int s, int quality,
+                              uint8_t* out, size_t cap, size_t* out_size);
 /* lines: [n][6] float64 = p0.x, p0.y, right.x, right.y, up.x, up.y in dewarped pixels; line l yields a
  * ysteps[l] x xsteps[l] x C image (rows already flipped as block.py:257 does) at out + offsets[l];
  * offsets: [n + 1] byte offsets.  Sample (i, j) sits at p0 + linspace(0, up, ysteps)[i] +

@@ -97,6 +97,8 @@ SIGNATURES = {
 	"ogd_page_destroy": (c_int, [c_void_p]),
 	"ogd_page_dewarp_u8": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_ssize_t, c_int]),
+	"ogd_page_dewarp_jpeg_gray": (c_int, [
+		c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
 	"ogd_line_images_u8": (c_int, [
 		c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
 		c_void_p]),
@@ -448,6 +450,20 @@ class DevicePage:
 			self.handle, _ptr(nodes), h, w, int(cell), float(sx), float(sy), _ptr(dst), dst.strides[0],
 			int(interpolation)))
 		return dst[:, :, 0] if self._squeeze else dst
+
+	def dewarp_jpeg(self, nodes, cell, quality=75):
+		"""The JPEG file of the dewarped page (what dewarp_jpeg_gray gives for the same pixels), gray pages only."""
+		nodes = _c(nodes, np.float32)
+		h, w = nodes.shape[:2]
+		lib, handle = load(), self.handle
+		return _jpeg_call(
+			lambda out, cap, size: lib.ogd_page_dewarp_jpeg_gray(
+				handle, _ptr(nodes), h, w, int(cell), int(quality), out, cap, size),
+			h * cell * w * cell)
+
+	@property
+	def nbytes(self):
+		return int(self.shape[0]) * int(self.shape[1]) * int(self.shape[2])
 
 	def line_images(self, nodes, cell, lines, xsteps, ysteps, interpolation=INTER_LINEAR):
 		"""lines: (n, 6) float64 rows p0.x p0.y right.x right.y up.x up.y -> list of n uint8 images."""

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <system_error>
 #include <thread>
+#include <cstdlib>
 #include <vector>
 
 namespace ogd {
@@ -19,8 +20,14 @@ namespace ogd {
 // is host-bound and these loops are independent per element.  Small n runs inline.
 template <class F>
 void parallel_ranges(int64_t n, int64_t grain, F fn) {
+  // OGD_THREADS (1 .. 4, read once): the stage runtime lowers it for workers that share few cores
+  static const int64_t cap = [] {
+    const char* e = getenv("OGD_THREADS");
+    const int v = e ? atoi(e) : 4;
+    return (int64_t)std::min(std::max(v, 1), 4);
+  }();
   const unsigned hw = std::thread::hardware_concurrency();
-  const int64_t want = std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n / std::max<int64_t>(grain, 1));
+  const int64_t want = std::min<int64_t>(std::min<int64_t>(cap, hw ? hw : 1), n / std::max<int64_t>(grain, 1));
   if (want <= 1) {
     fn((int64_t)0, n);
     return;

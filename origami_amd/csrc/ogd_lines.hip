@@ -182,6 +182,24 @@ int ogd_page_dewarp_u8(const ogd_page* page, const float* nodes, int h, int w, i
   return OGD_OK;
 }
 
+int ogd_page_dewarp_jpeg_gray(const ogd_page* page, const float* nodes, int h, int w, int s, int quality, uint8_t* out,
+                              size_t cap, size_t* out_size) {
+  OGD_REQUIRE(page && nodes && out_size, "null pointer");
+  OGD_REQUIRE(page->C == 1, "a gray page is needed, this one has %d channels", page->C);
+  OGD_REQUIRE(h >= 1 && w >= 1 && s >= 1, "bad node grid %dx%d cell %d", h, w, s);
+  OGD_REQUIRE((int64_t)h * s < 32768 && (int64_t)w * s < 32768, "dense grid too large");
+  OGD_TRY(ensure_device());
+  const int Hd = h * s, Wd = w * s;
+  const size_t nb = (size_t)h * w * 2 * sizeof(float);
+  DevBuf dn, ddst;
+  OGD_TRY(dn.alloc(nb));
+  OGD_TRY(ddst.alloc((size_t)Hd * Wd));
+  OGD_HIP(hipMemcpy(dn.p, nodes, nb, hipMemcpyHostToDevice));
+  OGD_TRY(ogd_dewarp_u8_dev(page->d, page->H, page->W, 1, page->stride, dn.as<float>(), h, w, s, 1.f, 1.f,
+                            ddst.as<uint8_t>(), (ptrdiff_t)Wd, OGD_INTER_LINEAR, nullptr));
+  return ogd_jpeg_encode_gray_dev(ddst.as<uint8_t>(), Hd, Wd, (ptrdiff_t)Wd, quality, out, cap, out_size, nullptr);
+}
+
 }  // extern "C"
 
 namespace {

@@ -390,13 +390,24 @@ class Grid:
 class Dewarper:
 	"""ref: dewarp.py:579-627."""
 
-	def __init__(self, im, grid, pixels=None):
+	def __init__(self, im, grid, pixels=None, device_page=None, warped=None):
 		"""pixels: the (H, W) uint8 array `im` was made from, if the caller still holds it (origami_amd.page.Page
-		after decoding a scan itself): spares the 48 MB copy PIL makes on the way back to numpy."""
-		self._im = im
+		after decoding a scan itself): spares the 48 MB copy PIL makes on the way back to numpy.
+		device_page: a callable giving the page resident in device memory (`_shim.DevicePage`, gray); `dewarped` and
+		`dewarped_jpeg` then work from it and `im` may be None, with `warped` a callable that makes the PIL image
+		should `dewarp_image` need its size (origami_amd.page: one decode and one upload per page and process)."""
+		self._im_ = im
+		self._warped = warped
 		self._grid = grid
 		self._dewarped = None
 		self._pixels = pixels
+		self._device_page = device_page
+
+	@property
+	def _im(self):
+		if self._im_ is None and self._warped is not None:
+			self._im_ = self._warped()
+		return self._im_
 
 	def _array(self):
 		return self._pixels if self._pixels is not None else np.asarray(self._im)
@@ -407,6 +418,9 @@ class Dewarper:
 
 	@property
 	def dewarped(self):
+		if self._dewarped is None and self._device_page is not None:
+			self._dewarped = PIL.Image.fromarray(self._device_page().dewarp(
+				self._grid.points("sample"), self._grid.resolution, interpolation=INTER_LINEAR))
 		if self._dewarped is None:
 			self._dewarped = PIL.Image.fromarray(_shim.dewarp_u8(
 				self._array(), self._grid.points("sample"), self._grid.resolution,
@@ -417,6 +431,8 @@ class Dewarper:
 		"""The file `self.dewarped.save(path.jpg)` writes (ref: origami/batch/core/io.py:606-610), as bytes:
 		dewarp and JPEG encoding both run on the device (ogd_dewarp_jpeg_gray), only the code stream comes
 		back.  Gray pages only (Page converts to "L", ref: origami/core/page.py:84)."""
+		if self._device_page is not None:
+			return self._device_page().dewarp_jpeg(self._grid.points("sample"), self._grid.resolution, quality)
 		if self._im.mode != "L":
 			raise ValueError("dewarped_jpeg needs an 'L' page, got mode %s" % self._im.mode)
 		return _shim.dewarp_jpeg_gray(
@@ -427,7 +443,10 @@ class Dewarper:
 		the size ratio.  The reference multiplies its cached dense grid in place (dewarp.py:621-623),
 		which leaks the scale into later users; here the scale is applied to a private copy inside
 		the kernel, i.e. the behaviour of the reference's first call."""
-		w0, h0 = self._im.size
+		if self._device_page is not None:
+			h0, w0 = self._device_page().shape[:2]
+		else:
+			w0, h0 = self._im.size
 		w1, h1 = im.size
 		return PIL.Image.fromarray(_shim.dewarp_u8(
 			np.array(im), self._grid.points("sample"), self._grid.resolution,

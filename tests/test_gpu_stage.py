@@ -412,15 +412,23 @@ def test_dewarped_image_stage_on_a_colour_jpeg_scan_with_restart_markers(gpu, tm
 		calls["fused"] += out is not None
 		return out
 
+	plain_from_jpeg = gpu.DevicePage.from_jpeg.__func__
+
+	def from_jpeg(cls, data):  # the route with resident pages (origami_amd.page.resident): decoded into an ogd_page
+		out = plain_from_jpeg(cls, data)
+		calls["fused"] += out is not None
+		return out
+
 	monkeypatch.setattr(gpu, "jpeg_decode_gray", decode)
 	monkeypatch.setattr(gpu, "jpeg_dewarp_jpeg_gray", fused)
+	monkeypatch.setattr(gpu.DevicePage, "from_jpeg", classmethod(from_jpeg))
 	assert np.array_equal(np.array(Page(page_path).warped), pixels)  # device decode == PIL decode + convert
 	assert calls["decode"] == 1
 	out = page_path.with_suffix(".out")
 	assert CliRunner().invoke(dewarp, [str(tmp_path), "--lock-strategy", "NONE"]).exit_code == 0
 	res = CliRunner().invoke(dewarp_image_stage, [str(tmp_path), "--lock-strategy", "NONE", "--plain"])
 	assert res.exit_code == 0, res.output
-	assert calls["fused"] == 1  # scan file in -> dewarped JPEG out, all on the device
+	assert calls["fused"] == 1  # scan file in -> dewarped JPEG out, all on the device (one call, or resident page + one call)
 	nodes = Grid.open(out / "dewarp.zip").points("sample")
 	want = PIL.Image.fromarray(odw2.dewarped(pixels, odw2.Grid(nodes, 25)))
 	ref = io.BytesIO()
