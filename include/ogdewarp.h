@@ -357,6 +357,17 @@ int ogd_inflate_zlib(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t cap,
 int ogd_deflate_raw(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out);
 int ogd_deflate_many(const uint8_t* in, const int64_t* offsets, int n, uint8_t* out, int64_t cap,
                      int64_t* out_offsets, uint32_t* crcs);
+/* PNG files of many small images in one call — the line images of a page (ref: origami/batch/export/lines.py:62-67:
+ * `im.save(f, format='png', optimize=True)` per line).  8-bit grey (channels = 1) or RGB (3), rows filtered by the
+ * minimum sum of absolute residuals, one IDAT chunk, the entropy coder of ogd_deflate_raw: the same pixels for any
+ * PNG reader, not PIL's bytes.  Image k: [heights[k]][widths[k]][channels] uint8 at in + offsets[k]; its file is
+ * written at out + out_starts[k], where out_starts[k + 1] - out_starts[k] >= ogd_png_bound(heights[k], widths[k],
+ * channels) bytes are free; out_sizes[k] receives its size, out_crcs[k] (may be NULL) the CRC-32 of the file (for
+ * the zip member that stores it).  Host code, up to OGD_THREADS (default 4) threads. */
+int64_t ogd_png_bound(int height, int width, int channels);
+int ogd_png_encode_many(const uint8_t* in, const int64_t* offsets, const int32_t* widths, const int32_t* heights,
+                        int channels, int n, uint8_t* out, const int64_t* out_starts, int64_t* out_sizes,
+                        uint32_t* out_crcs);
 /* The reading side (ref: origami/batch/core/io.py:142-144 and origami/core/dewarp.py:537-543 read the archives
  * through zipfile, one Python-level call per member): member k of an archive held in buf is the raw deflate stream
  * (methods[k] == 8) or the stored bytes (0) at buf[in_off[k] .. + in_len[k]); it is written to

@@ -147,12 +147,21 @@ class ZipWriter:
 		self._method = compression
 		self._level = compresslevel
 		self._members = []  # (name, data)
+		self._methods = []  # per member
+		self._crcs = []  # per member: given by the caller, or None
 		self._closed = False
 
-	def writestr(self, name, data):
+	def writestr(self, name, data, compress_type=None, crc=None):
+		"""compress_type (as zipfile's): ZIP_STORED for a member that is compressed already (a PNG file) — it is
+		written as it is instead of being run through the deflate coder to find that out.  crc: the CRC-32 of `data`
+		if the caller has it (stored members only; computed here otherwise)."""
 		if isinstance(data, str):
 			data = data.encode("utf-8")
+		if compress_type not in (None, zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED):
+			raise NotImplementedError("compression method %r" % (compress_type,))
 		self._members.append((name, bytes(data)))
+		self._methods.append(self._method if compress_type is None else compress_type)
+		self._crcs.append(None if crc is None else int(crc) & 0xFFFFFFFF)
 
 	def namelist(self):
 		return [name for name, _ in self._members]
@@ -170,27 +179,31 @@ class ZipWriter:
 		self._closed = True
 		if len(self._members) >= 0xFFFF or sum(len(d) + len(n) + 128 for n, d in self._members) >= (1 << 31):
 			with zipfile.ZipFile(self._f, "w", self._method, compresslevel=self._level) as zf:
-				for name, data in self._members:
-					zf.writestr(name, data)
+				for (name, data), method in zip(self._members, self._methods):
+					zf.writestr(name, data, compress_type=method)
 			return
 		t = time.localtime()
 		dos_time = t.tm_hour << 11 | t.tm_min << 5 | t.tm_sec // 2
 		dos_date = max(t.tm_year - 1980, 0) << 9 | t.tm_mon << 5 | t.tm_mday
 		out, central, offset = [], [], 0
-		if self._method == zipfile.ZIP_DEFLATED:
+		packed = [None] * len(self._members)
+		deflated = [k for k, m in enumerate(self._methods) if m == zipfile.ZIP_DEFLATED]
+		if deflated:
 			# libogdewarp's entropy-only deflate (csrc/ogd_deflate.h), all members in one call: coordinate text and
 			# float32 arrays hold next to nothing for a string matcher to find, and zlib's set-up per member alone
 			# costs more than coding a kilobyte
 			from ... import _shim
-			packed = _shim.deflate_many([data for _, data in self._members])
-		else:
-			packed = [(data, zlib.crc32(data)) for _, data in self._members]
-		for (name, data), (body, crc) in zip(self._members, packed):
+			for k, item in zip(deflated, _shim.deflate_many([self._members[k][1] for k in deflated])):
+				packed[k] = item
+		for k, (_, data) in enumerate(self._members):
+			if packed[k] is None:
+				packed[k] = (data, self._crcs[k] if self._crcs[k] is not None else zlib.crc32(data))
+		for (name, data), (body, crc), method in zip(self._members, packed, self._methods):
 			try:
 				raw, flags = name.encode("ascii"), 0
 			except UnicodeEncodeError:
 				raw, flags = name.encode("utf-8"), 0x0800
-			fields = (20, flags, self._method, dos_time, dos_date, crc, len(body), len(data), len(raw), 0)
+			fields = (20, flags, method, dos_time, dos_date, crc, len(body), len(data), len(raw), 0)
 			out.append(_LOCAL.pack(b"PK\x03\x04", *fields))
 			out.append(raw)
 			out.append(body)

@@ -67,3 +67,49 @@ def test_deflate_many_and_the_archives_built_from_it(tmp_path):
 	with open(tmp_path / "again.zip", "wb") as f:
 		Grid(nodes, 25).save(f)
 	assert (tmp_path / "again.zip").read_bytes()[:4] == b"PK\x03\x04"
+
+
+def test_png_writer_gives_the_pixels_back_through_pil_and_through_our_own_decoder():
+	"""ogd_png_encode_many (the line images of the export stage, ref: origami/batch/export/lines.py:62-67): every file
+	is a valid PNG holding exactly the pixels, for grey and RGB, rows of every filter type, and the degenerate sizes."""
+	import io
+	import PIL.Image
+	from origami_amd import _shim, synth
+	rng = np.random.default_rng(3)
+	page = synth.text_page(rng, (1500, 400))
+	grad = (np.add.outer(np.arange(40), np.arange(300)) % 256).astype(np.uint8)  # Paeth / Average rows
+	grey = [page[k * 48:(k + 1) * 48, :int(rng.integers(100, 1500))] for k in range(8)] + [
+		grad, grad.T.copy(), np.zeros((3, 300), np.uint8), np.full((1, 1), 7, np.uint8),
+		rng.integers(0, 256, size=(1, 50), dtype=np.uint8), rng.integers(0, 256, size=(50, 1), dtype=np.uint8),
+		rng.integers(0, 256, size=(64, 64), dtype=np.uint8)]
+	files = _shim.png_encode_many(grey)
+	assert len(files) == len(grey)
+	filters = set()
+	for im, data in zip(grey, files):
+		with PIL.Image.open(io.BytesIO(data)) as f:
+			f.verify()  # chunk CRCs
+		got = PIL.Image.open(io.BytesIO(data))
+		assert got.mode == "L" and np.array_equal(np.array(got), im)
+		assert np.array_equal(_shim.png_decode(data), im)
+		assert len(data) <= _shim.load().ogd_png_bound(im.shape[0], im.shape[1], 1)
+		raw = zlib.decompress(data[41:-16])  # one IDAT between IHDR (33 bytes in) and IEND: Adler-32 verified by zlib
+		rows = set(raw[::im.shape[1] + 1])
+		assert len(rows - {0, 1}) <= 1 or im.shape[0] == 1  # one filter per image (its first row may say None / Sub for Up / Paeth)
+		filters |= rows
+	assert len(filters) >= 2  # and the heuristic (one filter per image, from probe rows) does choose between them
+	rgb = [rng.integers(0, 256, size=(9, 31, 3), dtype=np.uint8), np.dstack([page[:40, :500], page[40:80, :500], page[80:120, :500]]),
+		rng.integers(0, 256, size=(1, 1, 3), dtype=np.uint8)]
+	for im, data in zip(rgb, _shim.png_encode_many(rgb)):
+		got = PIL.Image.open(io.BytesIO(data))
+		assert got.mode == "RGB" and np.array_equal(np.array(got), im)
+	assert _shim.png_encode_many([]) == []
+	with pytest.raises(TypeError):
+		_shim.png_encode_many([grey[0], rgb[0]])
+	# text lines: within a few per cent of PIL's optimize=True
+	ours = sum(len(d) for d in files[:8])
+	ref = 0
+	for im in grey[:8]:
+		b = io.BytesIO()
+		PIL.Image.fromarray(im).save(b, format="png", optimize=True)
+		ref += len(b.getvalue())
+	assert ours < 1.10 * ref

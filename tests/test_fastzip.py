@@ -103,3 +103,25 @@ def test_writer_leaves_nothing_behind_when_the_block_raises():
 			zf.writestr("a", b"1")
 			raise RuntimeError("stage failed")
 	assert f.getvalue() == b""
+
+
+def test_members_of_one_archive_may_be_stored_or_deflated():
+	"""writestr(..., compress_type=ZIP_STORED) for a member that is compressed already (the PNG files of the line
+	export, ref: origami/batch/export/lines.py:62-67): zipfile and fastzip both read the mixed archive."""
+	import io
+	import os
+	blob = os.urandom(5000)
+	f = io.BytesIO()
+	with fastzip.ZipWriter(f, zipfile.ZIP_DEFLATED) as zf:
+		zf.writestr("a/text.wkt", "POLYGON ((0 0, 1 0, 1 1, 0 0))" * 40)
+		zf.writestr("a/image.png", blob, compress_type=zipfile.ZIP_STORED)
+		zf.writestr("b.json", b"{}", compress_type=zipfile.ZIP_DEFLATED)
+		zf.writestr("a/other.png", blob[:100], compress_type=zipfile.ZIP_STORED, crc=zlib.crc32(blob[:100]))  # CRC given by the caller
+	with zipfile.ZipFile(io.BytesIO(f.getvalue())) as zf:
+		assert zf.testzip() is None
+		infos = {i.filename: i for i in zf.infolist()}
+		assert infos["a/image.png"].compress_type == zipfile.ZIP_STORED and infos["a/image.png"].compress_size == 5000
+		assert infos["a/text.wkt"].compress_type == zipfile.ZIP_DEFLATED and infos["a/text.wkt"].compress_size < 1200 * 0.6  # entropy coding only: no string matching
+		assert zf.read("a/image.png") == blob and zf.read("a/other.png") == blob[:100]
+	zr = fastzip.ZipReader(io.BytesIO(f.getvalue()))
+	assert dict(zr.items())["a/image.png"] == blob and zr.read("b.json") == b"{}"
