@@ -51,7 +51,16 @@ template <class MapSrc, int C> struct TileShape { static constexpr int LX = 16, 
 #endif
 template <> struct TileShape<MapGlobal, 3> { static constexpr int LX = K2MC_LX, RPT = K2MC_RPT, LDSW = RL_SHEAR3 ? K2C3_LDSW : K2MC_LDSW; };
 template <> struct TileShape<MapGlobal, 4> { static constexpr int LX = K2MC_LX, RPT = K2MC_RPT, LDSW = K2MC_LDSW; };
-template <int C> struct TileShape<MapNodes, C> { static constexpr int LX = 8, RPT = 4, LDSW = C == 1 ? 4096 : 8192; };
+#ifndef FUSED_LX
+#define FUSED_LX 8
+#endif
+#ifndef FUSED_RPT
+#define FUSED_RPT 4
+#endif
+#ifndef FUSED_LDSW1
+#define FUSED_LDSW1 4096
+#endif
+template <int C> struct TileShape<MapNodes, C> { static constexpr int LX = FUSED_LX, RPT = FUSED_RPT, LDSW = C == 1 ? FUSED_LDSW1 : 8192; };
 template <int C> struct TileShape<MapNodesUnit, C> : TileShape<MapNodes, C> {};
 
 template <int C, class MapSrc>
