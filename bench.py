@@ -546,11 +546,56 @@ def stage_leg(n_gpus, n_pages=96, workers=(1, 8), n_polygons=400):
 				"ms_per_page": round(dt / n_pages * 1e3, 2), "MP_per_s": round(n_pages * W * H / 1e6 / dt, 1),
 				"one_page_run_seconds": round(t_start, 3), "ms_per_page_beyond_the_first": round(steady * 1e3, 2),
 				"MP_per_s_beyond_the_first": round(W * H / 1e6 / steady, 1)})
+		out["pixel_stages"] = pixel_stages_leg(env)
 	finally:
 		shutil.rmtree(root, ignore_errors=True)
 		if "empty" in locals():
 			shutil.rmtree(empty, ignore_errors=True)
 	return out
+
+
+def pixel_stages_leg(env, n_pages=8, n_lines=300):
+	"""The two stages that only look at pixels, chained in one child process over resident pages
+	(python -m origami_amd.batch.chain: `utils.dewarp` writes annotation.dewarped.jpg, `export.lines` cuts the page's
+	lines and writes their PNG files): `.jpg` scans of 6000x8000 with `n_lines` text lines + table cells each, wall
+	clock incl. start-up, and the same on one page beside it."""
+	import shutil
+	import subprocess
+	import tempfile
+	import PIL.Image
+	from origami_amd import synth
+	W, H = PAGE
+	root = Path(tempfile.mkdtemp(prefix="ogd_bench_pixels_"))
+	one = Path(tempfile.mkdtemp(prefix="ogd_bench_pixels1_"))
+	try:
+		rng = np.random.default_rng(5100)
+		pixels = synth.text_page(rng, (W, H))
+		for k in range(n_pages):
+			path = (one if k == 0 else root) / ("page%04d.jpg" % k)
+			PIL.Image.fromarray(np.roll(pixels, 41 * k, axis=1)).save(path, quality=90)
+			synth.write_reliable_stage(path, rng, synth.Warp((W, H), 0.03, 0.02, 1 + k % 2, 2 - k % 2).node_grid(25), 25,
+				n_lines=n_lines, n_table_lines=4)
+		shutil.copyfile(one / "page0000.jpg", root / "page0000.jpg")
+		shutil.copytree(one / "page0000.out", root / "page0000.out")
+		def run(where):
+			cmd = [sys.executable, "-m", "origami_amd.batch.chain", str(where), "--stage", "utils.dewarp --lock-strategy NONE",
+				"--stage", "export.lines --lock-strategy NONE"]
+			t0 = time.perf_counter()
+			r = subprocess.run(cmd, cwd=str(ROOT), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+			return time.perf_counter() - t0, r
+		t_one, _ = run(one)
+		dt, r = run(root)
+		done = sum((root / ("page%04d.out" % i) / "images.lines.dewarped.zip").exists() and
+			(root / ("page%04d.out" % i) / "annotation.dewarped.jpg").exists() for i in range(n_pages))
+		if r.returncode != 0 or done != n_pages:
+			return {"error": r.stdout.decode(errors="replace")[-400:]}
+		steady = max(dt - t_one, 1e-9) / max(n_pages - 1, 1)
+		return {"what": "utils.dewarp + export.lines chained in one child process (origami_amd.batch.chain) on %d .jpg scans 6000x8000 with %d line images each; wall clock incl. start-up" % (n_pages, n_lines + 12),
+			"seconds": round(dt, 3), "one_page_run_seconds": round(t_one, 3), "ms_per_page_beyond_the_first": round(steady * 1e3, 1),
+			"MP_per_s_beyond_the_first": round(W * H / 1e6 / steady, 1)}
+	finally:
+		shutil.rmtree(root, ignore_errors=True)
+		shutil.rmtree(one, ignore_errors=True)
 
 
 def launch_ranks(n):
