@@ -360,12 +360,12 @@ int ogd_deflate_many(const uint8_t* in, const int64_t* offsets, int n, uint8_t* 
 /* PNG files of many small images in one call — the line images of a page (ref: origami/batch/export/lines.py:62-67:
  * `im.save(f, format='png', optimize=True)` per line).  8-bit grey (channels = 1) or RGB (3), rows filtered by the
  * minimum sum of absolute residuals, one IDAT chunk, the entropy coder of ogd_deflate_raw: the same pixels for any
- * PNG reader, not PIL's bytes.  Image k: [heights[k]][widths[k]][channels] uint8 at in + offsets[k]; its file is
+ * PNG reader, not PIL's bytes.  Image k: [heights[k]][widths[k]][channels] uint8, contiguous, at images[k]; its file is
  * written at out + out_starts[k], where out_starts[k + 1] - out_starts[k] >= ogd_png_bound(heights[k], widths[k],
  * channels) bytes are free; out_sizes[k] receives its size, out_crcs[k] (may be NULL) the CRC-32 of the file (for
  * the zip member that stores it).  Host code, up to OGD_THREADS (default 4) threads. */
 int64_t ogd_png_bound(int height, int width, int channels);
-int ogd_png_encode_many(const uint8_t* in, const int64_t* offsets, const int32_t* widths, const int32_t* heights,
+int ogd_png_encode_many(const uint8_t* const* images, const int32_t* widths, const int32_t* heights,
                         int channels, int n, uint8_t* out, const int64_t* out_starts, int64_t* out_sizes,
                         uint32_t* out_crcs);
 /* The reading side (ref: origami/batch/core/io.py:142-144 and origami/core/dewarp.py:537-543 read the archives

@@ -159,7 +159,8 @@ class ZipWriter:
 			data = data.encode("utf-8")
 		if compress_type not in (None, zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED):
 			raise NotImplementedError("compression method %r" % (compress_type,))
-		self._members.append((name, bytes(data)))
+		# a memoryview is kept as it is (the PNG files of the line export are views into the encoder's one buffer)
+		self._members.append((name, data if isinstance(data, (bytes, memoryview)) else bytes(data)))
 		self._methods.append(self._method if compress_type is None else compress_type)
 		self._crcs.append(None if crc is None else int(crc) & 0xFFFFFFFF)
 
@@ -215,4 +216,4 @@ class ZipWriter:
 		n = len(self._members)
 		out.append(directory)
 		out.append(_EOCD.pack(b"PK\x05\x06", 0, 0, n, n, len(directory), offset, 0))
-		self._f.write(b"".join(out))
+		self._f.writelines(out)  # (no joined copy of the whole archive)

@@ -36,6 +36,16 @@ def png_bytes(image):
 	return data.getvalue()
 
 
+def _pixels_of(image):
+	"""The array a line image was made from, if origami_amd.block.dewarped_line_images left it on the image (a PIL
+	operation on the image gives a new object without it), else a copy out of PIL."""
+	import numpy as np
+	a = getattr(image, "_ogd_pixels", None)
+	if a is not None and a.dtype == np.uint8 and a.shape[:2] == (image.height, image.width) and a.flags.c_contiguous:
+		return a
+	return np.asarray(image)
+
+
 def png_files(items):
 	"""(path, PNG file, its CRC-32 or None) for the (path, PIL image) items of a page, in their order.  The reference saves every line
 	with PIL (ref: origami/batch/export/lines.py:62-67: `im.save(f, format='png', optimize=True)`, zlib at level 9):
@@ -50,7 +60,7 @@ def png_files(items):
 	for mode in ("L", "RGB"):
 		picked = [k for k, (_, im) in enumerate(items) if im.mode == mode and im.width > 0 and im.height > 0]
 		if picked:
-			for k, item in zip(picked, _shim.png_encode_many([np.asarray(items[k][1]) for k in picked], with_crc=True)):
+			for k, item in zip(picked, _shim.png_encode_many([_pixels_of(items[k][1]) for k in picked], with_crc=True, views=True)):
 				files[k] = item
 	for k, (path, im) in enumerate(items):
 		yield (path,) + (files[k] if files[k] is not None else (png_bytes(im), None))

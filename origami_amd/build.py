@@ -18,7 +18,7 @@ LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libogdewarp.so"
 
 SOURCES = ["ogd_runtime.hip", "ogd_grid.hip", "ogd_remap.hip", "ogd_tri.hip", "ogd_lines.hip", "ogd_lattice.hip", "ogd_delaunay.hip", "ogd_png.hip", "ogd_deflate.hip", "ogd_march.hip", "ogd_wkt.hip", "ogd_jpeg.hip", "ogd_jpeg_dec.hip"]
-HEADERS = ["ogd_common.h", "ogd_lawson.h", "ogd_inflate.h", "ogd_deflate.h", "ogd_tri_dev.h", "ogd_resize_math.h", "ogd_grid_lines.h", "ogd_remap_math.h", "ogd_remap_lds.h", "../../include/ogdewarp.h"]
+HEADERS = ["ogd_common.h", "ogd_lawson.h", "ogd_inflate.h", "ogd_deflate.h", "ogd_checksum.h", "ogd_tri_dev.h", "ogd_resize_math.h", "ogd_grid_lines.h", "ogd_remap_math.h", "ogd_remap_lds.h", "../../include/ogdewarp.h"]
 
 # -ffp-contract=off: the parity-critical fp32/fp64 chains must round exactly like the CPU libraries
 # they replace (OpenCV resize, scipy interpnd); the kernels additionally spell those chains with

@@ -124,10 +124,23 @@ inline void assign_codes(const uint8_t* lens, int n, uint32_t* out) {
 // One block of literals.  Returns false if the output is full.
 inline bool write_block(BitWriter& w, const uint8_t* in, int n, bool last) {
   uint32_t freq[257] = {0};
-  for (int i = 0; i < n; ++i) ++freq[in[i]];
+  {  // four histograms: runs of one value (blank paper) do not serialise on one counter
+    uint32_t f1[256] = {0}, f2[256] = {0}, f3[256] = {0};
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      ++freq[in[i]];
+      ++f1[in[i + 1]];
+      ++f2[in[i + 2]];
+      ++f3[in[i + 3]];
+    }
+    for (; i < n; ++i) ++freq[in[i]];
+    for (int s = 0; s < 256; ++s) freq[s] += f1[s] + f2[s] + f3[s];
+  }
   freq[256] = 1;  // end of block
   uint8_t lens[257 + 1];
-  code_lengths(freq, 257, 15, lens);
+  // literal codes of at most 12 bits: four of them and the up to 7 bits pending fit one 64-bit word (below); the
+  // cost against 15 bits is nil on anything but a pathological histogram
+  code_lengths(freq, 257, 12, lens);
   uint64_t body_bits = 0;
   for (int s = 0; s < 257; ++s) body_bits += (uint64_t)freq[s] * lens[s];
   // the code lengths, run-length coded with the symbols 16 (repeat), 17 / 18 (zeros); one distance code of length 0
@@ -192,8 +205,38 @@ inline bool write_block(BitWriter& w, const uint8_t* in, int n, bool last) {
     else if (sym[i] == 17) w.put(extra[i], 3);
     else if (sym[i] == 18) w.put(extra[i], 7);
   }
-  // the literals: two per put where their codes fit 32 bits together (always: 2 x 15)
   int i = 0;
+  // the literals, four per 64-bit word: no branch and one unaligned 8-byte store per four symbols, while the
+  // output has room for the whole block body and the store's overshoot (else: the careful loop below all the way)
+  if (!w.full && (uint64_t)(w.end - w.p) >= body_bits / 8 + 24) {
+    uint64_t acc = w.acc;
+    int nb = w.n;  // < 32 pending bits
+    uint8_t* p = w.p;
+    while (nb >= 8) {  // down to < 8 pending bits
+      *p++ = (uint8_t)acc;
+      acc >>= 8;
+      nb -= 8;
+    }
+    for (; i + 4 <= n; i += 4) {
+      const uint32_t a = code[in[i]], b = code[in[i + 1]], c = code[in[i + 2]], d = code[in[i + 3]];
+      // the symbols are paired off first: two steps through the bit position per word instead of four
+      const int la = (int)(a >> 16), lc = (int)(c >> 16);
+      const uint64_t ab = (uint64_t)(a & 0xffff) | (uint64_t)(b & 0xffff) << la;
+      const uint64_t cd = (uint64_t)(c & 0xffff) | (uint64_t)(d & 0xffff) << lc;
+      const int lab = la + (int)(b >> 16), lcd = lc + (int)(d >> 16);
+      acc |= ab << nb;
+      acc |= cd << (nb + lab);
+      nb += lab + lcd;  // <= 7 + 48
+      std::memcpy(p, &acc, 8);
+      p += nb >> 3;
+      acc >>= nb & ~7;
+      nb &= 7;
+    }
+    w.p = p;
+    w.acc = acc;
+    w.n = nb;
+  }
+  // (the rest, or everything:) two per put where their codes fit 32 bits together (always: 2 x 15)
   for (; i + 2 <= n; i += 2) {
     const uint32_t a = code[in[i]], b = code[in[i + 1]];
     const int la = (int)(a >> 16), lb = (int)(b >> 16);

@@ -15,34 +15,8 @@
 namespace ogd {
 namespace {
 
-// CRC-32 (IEEE 802.3, the zip / PNG polynomial), eight bytes per step
-struct CrcTables {
-  uint32_t t[8][256];
-  CrcTables() {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-      t[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-      for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
-  }
-};
-
-uint32_t crc32(const uint8_t* p, int64_t n) {
-  static const CrcTables T;
-  uint32_t c = 0xFFFFFFFFu;
-  for (; n >= 8; n -= 8, p += 8) {
-    uint32_t lo, hi;
-    std::memcpy(&lo, p, 4);
-    std::memcpy(&hi, p + 4, 4);
-    lo ^= c;
-    c = T.t[7][lo & 0xff] ^ T.t[6][(lo >> 8) & 0xff] ^ T.t[5][(lo >> 16) & 0xff] ^ T.t[4][lo >> 24] ^
-        T.t[3][hi & 0xff] ^ T.t[2][(hi >> 8) & 0xff] ^ T.t[1][(hi >> 16) & 0xff] ^ T.t[0][hi >> 24];
-  }
-  for (; n > 0; --n) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xff];
-  return ~c;
-}
+// CRC-32 (IEEE 802.3, the zip / PNG polynomial): ogd_checksum.h (carry-less multiplication where the CPU has it)
+inline uint32_t crc32(const uint8_t* p, int64_t n) { return checksum::crc32(p, n); }
 
 inline void put_be32(uint8_t* p, uint32_t v) {
   p[0] = (uint8_t)(v >> 24), p[1] = (uint8_t)(v >> 16), p[2] = (uint8_t)(v >> 8), p[3] = (uint8_t)v;
@@ -225,26 +199,26 @@ int ogd_deflate_many(const uint8_t* in, const int64_t* offsets, int n, uint8_t* 
 // the export stage's time once the images themselves come from one kernel launch).  Rows filtered by the minimum
 // sum of absolute residuals, then the entropy coder of ogd_deflate.h (no string matching: scanned text is noise
 // around a few grey levels, its filtered rows hold next to no repeats).  Image k: [heights[k]][widths[k]][channels]
-// at in + offsets[k]; its file goes to out + out_starts[k] (room: out_starts[k + 1] - out_starts[k], at least
+// contiguous at images[k]; its file goes to out + out_starts[k] (room: out_starts[k + 1] - out_starts[k], at least
 // ogd_png_bound of the image), out_sizes[k] receives the file's size and out_crcs[k] (may be null) its CRC-32, which
 // a zip archive that stores the file wants.  Images are independent: up to OGD_THREADS threads.
 int64_t ogd_png_bound(int height, int width, int channels) { return png_bound(height, width, channels); }
 
-int ogd_png_encode_many(const uint8_t* in, const int64_t* offsets, const int32_t* widths, const int32_t* heights,
+int ogd_png_encode_many(const uint8_t* const* images, const int32_t* widths, const int32_t* heights,
                         int channels, int n, uint8_t* out, const int64_t* out_starts, int64_t* out_sizes,
                         uint32_t* out_crcs) {
-  OGD_REQUIRE(n >= 0 && (n == 0 || (in && offsets && widths && heights && out && out_starts && out_sizes)), "bad argument");
+  OGD_REQUIRE(n >= 0 && (n == 0 || (images && widths && heights && out && out_starts && out_sizes)), "bad argument");
   OGD_REQUIRE(channels == 1 || channels == 3, "PNG writer: %d channels (1 or 3)", channels);
   for (int k = 0; k < n; ++k) {
     OGD_REQUIRE(widths[k] >= 1 && heights[k] >= 1 && widths[k] < (1 << 24) && heights[k] < (1 << 24), "image %d: bad size %dx%d", k, widths[k], heights[k]);
-    OGD_REQUIRE(offsets[k + 1] - offsets[k] == (int64_t)widths[k] * heights[k] * channels, "image %d: offsets do not match its size", k);
+    OGD_REQUIRE(images[k] != nullptr, "image %d: null pointer", k);
     OGD_REQUIRE(out_starts[k + 1] - out_starts[k] >= png_bound(heights[k], widths[k], channels), "image %d: output room too small", k);
   }
   std::atomic<int> failed{0};
   parallel_ranges(n, 4, [&](int64_t b, int64_t e) {
     std::vector<uint8_t> scratch;
     for (int64_t k = b; k < e; ++k) {
-      const int64_t size = png_encode_one(in + offsets[k], heights[k], widths[k], channels, out + out_starts[k],
+      const int64_t size = png_encode_one(images[k], heights[k], widths[k], channels, out + out_starts[k],
                                           out_starts[k + 1] - out_starts[k], scratch);
       if (size < 0) failed.store(1);
       out_sizes[k] = size;

@@ -11,6 +11,7 @@
 // loop takes over, so corrupt or truncated input ends in an error code and never in an out-of-bounds access
 // (tools/inflate_fuzz.cpp runs it under AddressSanitizer).
 #pragma once
+#include "ogd_checksum.h"
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -417,24 +418,8 @@ inline int inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out0, int64_t c
   return OK;
 }
 
-// Adler-32 continued from `adler` (1 for a fresh sum).  Blocks of 4096 bytes as two plain reductions (sum and
-// position-weighted sum), which the compiler vectorises; 255 * 4096 * 4097 / 2 + 4096 * 65520 < 2^32.
-inline uint32_t adler32(uint32_t adler, const uint8_t* p, int64_t n) {
-  uint32_t a = adler & 0xffff, b = adler >> 16;
-  while (n > 0) {
-    const uint32_t k = (uint32_t)(n < 4096 ? n : 4096);
-    uint32_t sum = 0, wsum = 0;
-    for (uint32_t i = 0; i < k; ++i) {
-      sum += p[i];
-      wsum += (k - i) * p[i];
-    }
-    b = (b + k * a + wsum) % 65521;
-    a = (a + sum) % 65521;
-    p += k;
-    n -= k;
-  }
-  return (b << 16) | a;
-}
+// Adler-32 continued from `adler` (1 for a fresh sum): ogd_checksum.h (SSSE3 where the CPU has it).
+inline uint32_t adler32(uint32_t adler, const uint8_t* p, int64_t n) { return checksum::adler32(adler, p, n); }
 
 // zlib stream (2-byte header, deflate data, Adler-32 of the output)
 // verify: check the Adler-32 here; otherwise *adler_out (may be null) receives the stored value for a caller that

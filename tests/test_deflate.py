@@ -113,3 +113,31 @@ def test_png_writer_gives_the_pixels_back_through_pil_and_through_our_own_decode
 		PIL.Image.fromarray(im).save(b, format="png", optimize=True)
 		ref += len(b.getvalue())
 	assert ours < 1.10 * ref
+
+
+def test_checksums_equal_zlibs_over_lengths_and_alignments():
+	"""csrc/ogd_checksum.h: CRC-32 by carry-less multiplication and Adler-32 by SSSE3 multiply-add where the CPU has
+	them (else the portable forms) — through the entry points that use them: the member CRCs of ogd_deflate_many and
+	the Adler-32 check of ogd_inflate_zlib, on lengths around every block boundary of the vector code."""
+	import ctypes
+	rng = np.random.default_rng(8)
+	blob = rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()
+	lengths = list(range(0, 200)) + [255, 256, 257, 1023, 4095, 4096, 4097, 5535, 5536, 5537, 5552, 11072, 11073, 65535, 65536, 65537, 200001]
+	members = []
+	for k, n in enumerate(lengths):
+		off = (7 * k) % 61
+		members.append(blob[off:off + n])
+	members.append(b"\xff" * 100000)  # the sums at their largest
+	for data, (stream, crc) in zip(members, _shim.deflate_many(members)):
+		assert crc == zlib.crc32(data), len(data)
+		assert zlib.decompress(stream, -15) == data
+	lib = _shim.load()
+	for data in members[::3] + [members[-1]]:
+		z = zlib.compress(data, 1)
+		out = np.empty(max(len(data), 1), dtype=np.uint8)
+		n_out = ctypes.c_int64(0)
+		assert lib.ogd_inflate_zlib(z, len(z), out.ctypes.data, out.size, ctypes.byref(n_out)) == 0, len(data)
+		assert out[:n_out.value].tobytes() == data
+		bad = bytearray(z)
+		bad[-1] ^= 1  # a wrong Adler-32 is noticed
+		assert lib.ogd_inflate_zlib(bytes(bad), len(bad), out.ctypes.data, out.size, ctypes.byref(n_out)) != 0
