@@ -117,6 +117,19 @@ def main():
 			pr.disable()
 			pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 			pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+			if os.environ.get("STAGE_PROFILE_SERIAL"):
+				# the same with the side thread's half in the main thread, so that the profile holds a page's whole host work
+				from origami_amd.batch.core.processor import Processor
+				from origami_amd.batch.detect.dewarp import DewarpProcessor
+				DewarpProcessor.prefetch = Processor.prefetch
+				run(True)
+				pr = cProfile.Profile()
+				pr.enable()
+				dt = run(True)
+				pr.disable()
+				print("without prefetch, profiled: %.1f ms/page" % (1e3 * dt / n_pages))
+				pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+				pstats.Stats(pr).sort_stats("tottime").print_stats(40)
 	finally:
 		shutil.rmtree(root, ignore_errors=True)
 
