@@ -41,6 +41,7 @@ PAGE = (6000, 8000)  # (W, H)
 CELL = 25
 N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is ~2 s each)
 N_POLYGONS = 400
+GROUP = int(os.environ.get("BENCH_GROUP", "8"))  # pages per group of a step: K1a for the group, then K2 for it (run_step)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
 TRAFFIC_JSON = ROOT / "profiles" / "r03" / "k2_traffic.json"  # rocprofv3 --pmc passes (tools/pmc.sh, tools/k2_traffic.py)
@@ -132,7 +133,9 @@ def build_workload(torch, shim, dev, n_pages, rank):
 
 	h, w = warps[0]["nodes"].shape[:2]
 	Hd, Wd = h * CELL, w * CELL
-	dense = torch.empty((Hd, Wd, 2), dtype=torch.float32, device=dev)
+	# GROUP dense grids: a step takes the batch in groups of GROUP pages, K1a for the group and then K2 for it
+	# (run_step); 8 x 392 MB of the 288 GB
+	dense = [torch.empty((Hd, Wd, 2), dtype=torch.float32, device=dev) for _ in range(min(GROUP, n_pages))]
 	# one allocation per dewarped page (a page of 6075 x 8075 bytes is an odd number of bytes long: packed pages would
 	# start at every alignment; K2 aligns its stores to the output whatever that is, its map loads follow when it can)
 	outs = [torch.empty((Hd, Wd), dtype=torch.uint8, device=dev) for _ in range(n_pages)]
@@ -143,24 +146,34 @@ def run_step(torch, lib, check, wl, stream, events=None, side_stream=None):
 	W, H = PAGE
 	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
 	n_pages = wl["pages"].shape[0]
-	dense_p = wl["dense"].data_ptr()
-	for p in range(n_pages):
-		wp = wl["warps"][p % len(wl["warps"])]
-		poly = wl["polys"][p]
-		check(lib.ogd_grid_fill_dev(wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0, dense_p, stream))
-		if events is not None:
-			e0 = torch.cuda.Event(enable_timing=True)
-			e1 = torch.cuda.Event(enable_timing=True)
-			e0.record()
-		check(lib.ogd_remap_u8_dev(
-			wl["pages"][p].data_ptr(), H, W, 1, W, dense_p, Hd, Wd, wl["outs"][p].data_ptr(), Wd, 1, stream))
-		if events is not None:
-			e1.record()
-			events.append((e0, e1))
-		# K3 depends on nothing K1a / K2 produce: it runs on its own stream and fills the gaps
-		check(lib.ogd_tri_eval_ragged_dev(
-			wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
-			poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream or stream))
+	# Groups of GROUP pages: K1a for every page of the group, each into a dense grid of its own, then K2 for them.
+	# Page by page through ONE grid buffer (rounds 1 - 2) a K2 starts while the K1a before it is still draining its
+	# 392 MB of stores: tools/phase_order.py, profiles/r03/ab_phase_order.log — 158.0 us per page (K1a + K2) page by
+	# page, 154.2 in groups of 4 - 8, 158 in groups of 16, 160.5 with all 64 K1a first; the whole step on one box
+	# (BENCH_GROUP=1 / 8, ac_group.log): 10.73 -> 10.61 ms, K2 92.7 -> 91.5 us.
+	dense = wl["dense"]
+	for g0 in range(0, n_pages, len(dense)):
+		group = range(g0, min(g0 + len(dense), n_pages))
+		for p in group:
+			wp = wl["warps"][p % len(wl["warps"])]
+			check(lib.ogd_grid_fill_dev(wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0, dense[p - g0].data_ptr(), stream))
+		for p in group:
+			wp = wl["warps"][p % len(wl["warps"])]
+			poly = wl["polys"][p]
+			if events is not None:
+				e0 = torch.cuda.Event(enable_timing=True)
+				e1 = torch.cuda.Event(enable_timing=True)
+				e0.record()
+			check(lib.ogd_remap_u8_dev(
+				wl["pages"][p].data_ptr(), H, W, 1, W, dense[p - g0].data_ptr(), Hd, Wd, wl["outs"][p].data_ptr(), Wd, 1, stream))
+			if events is not None:
+				e1.record()
+				events.append((e0, e1))
+			# K3 depends on nothing K1a / K2 produce: it runs on its own stream and fills the gaps (on the main stream
+			# after the group's K2 launches a step takes 5 % longer; beside the K1a launches the same: ac_k3_modes.log)
+			check(lib.ogd_tri_eval_ragged_dev(
+				wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
+				poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream or stream))
 
 
 def fused_pass(torch, lib, check, wl, stream, side_stream, repeats=2):
@@ -757,9 +770,10 @@ def main():
 			"dtype": "u8",
 			"data": "synthetic",
 			"config": {
-				"workload": "configs[1]: %d synthetic 6000x8000 grayscale pages per GPU, cell %d, dense grid %dx%d, %d contour rings/page; K1a grid fill + K2 remap + K3 contour warp per page" % (
-					args.pages, CELL, Wd, Hd, N_POLYGONS),
+				"workload": "configs[1]: %d synthetic 6000x8000 grayscale pages per GPU, cell %d, dense grid %dx%d, %d contour rings/page; K1a grid fill + K2 remap + K3 contour warp per page, taken in groups of %d pages (K1a for the group, then K2 + K3)" % (
+					args.pages, CELL, Wd, Hd, N_POLYGONS, GROUP),
 				"pages_per_gpu": args.pages,
+				"pages_per_group": GROUP,
 				"distinct_warps": len(wl["warps"]),
 				"parallelism": "page-sharded x%d, no collective" % world,
 			},

@@ -20,6 +20,9 @@ namespace ogd {
 constexpr int GF_THREADS = 512;
 constexpr int GF_ROWS = 4;
 constexpr int GL_COLS = 496, GL_ROWS = 8;  // grid_fill_lines_kernel's tile; its rows must not exceed the cell size
+#ifndef GL_THREADS
+#define GL_THREADS 256  // 512 is faster alone and slower with the K2 that follows (ogd_grid_lines.h); tools/build_variant_all.sh
+#endif
 
 typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
@@ -111,7 +114,7 @@ int ogd_grid_fill_rows_dev(const float* d_nodes, int h, int w, int s, float sx, 
     // follows (tools/kbench "lines", profiles/r02/m_kbench_k1a_lines.log)
     dim3 lgrid((Wd + 15 + GL_COLS - 1) / GL_COLS, (nrows + GL_ROWS - 1) / GL_ROWS);
     OGD_REQUIRE(lgrid.y <= 65535u, "dense grid too tall");
-    hipLaunchKernelGGL((grid_fill_lines_kernel<GL_COLS, GL_ROWS, true>), lgrid, dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL((grid_fill_lines_kernel<GL_COLS, GL_ROWS, true, GL_THREADS>), lgrid, dim3(GL_THREADS), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy,
                        reinterpret_cast<float2*>(d_out), y0, y0 + nrows, Wd);
     return check_launch("grid_fill_lines_kernel");

@@ -24,7 +24,8 @@ typedef float gl_f4 __attribute__((ext_vector_type(4)));
 // g + RG, ... of the band.  A store-only kernel reaches 6.7 TB/s with one 16-byte store per thread, 6.0 with two,
 // 5.4 with eight (tools/kbench "chunk fill"), and 512 threads do run this kernel faster by itself (64 against 75 us
 // per broadsheet page) — but the K2 that reads the map next then takes longer by more than that (169 against 164 us
-// for the pair), so the library launches 256 threads (profiles/r02/m_kbench_k1a_lines.log).
+// for the pair), so the library launches 256 threads (profiles/r02/m_kbench_k1a_lines.log; round 3, with the K2
+// launches of a group of pages behind the K1a launches of that group: 158.5 against 154.2 us, profiles/r03/ab_phase_order.log).
 // The grid is (ceil((Wd + 15) / TW), ceil(rows / TR)).
 template <int TW, int TR, bool NT, int NTHREADS = 256>
 __global__ __launch_bounds__(NTHREADS) void grid_fill_lines_kernel(const float2* __restrict__ nodes, int h, int w,
