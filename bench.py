@@ -41,6 +41,11 @@ PAGE = (6000, 8000)  # (W, H)
 CELL = 25
 N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is ~2 s each)
 N_POLYGONS = 400
+# K2 launches bracketed by HIP events inside the timed steps: every third (3 and GROUP are coprime, so every position
+# of a group is sampled alike).  The brackets are not free — events around every launch make a step 2.8 % longer
+# (10.64 against 10.36 ms, profiles/r03/ad_bench_events.log) and the K2 they time 0.6 us shorter, because a bracketed
+# launch cannot begin under the tail of the one before it.
+EVENT_EVERY = int(os.environ.get("BENCH_EVENT_EVERY", "3"))
 GROUP = int(os.environ.get("BENCH_GROUP", "8"))  # pages per group of a step: K1a for the group, then K2 for it (run_step)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
@@ -160,13 +165,14 @@ def run_step(torch, lib, check, wl, stream, events=None, side_stream=None):
 		for p in group:
 			wp = wl["warps"][p % len(wl["warps"])]
 			poly = wl["polys"][p]
-			if events is not None:
+			ev = events is not None and p % EVENT_EVERY == 0
+			if ev:
 				e0 = torch.cuda.Event(enable_timing=True)
 				e1 = torch.cuda.Event(enable_timing=True)
 				e0.record()
 			check(lib.ogd_remap_u8_dev(
 				wl["pages"][p].data_ptr(), H, W, 1, W, dense[p - g0].data_ptr(), Hd, Wd, wl["outs"][p].data_ptr(), Wd, 1, stream))
-			if events is not None:
+			if ev:
 				e1.record()
 				events.append((e0, e1))
 			# K3 depends on nothing K1a / K2 produce: it runs on its own stream and fills the gaps (on the main stream
@@ -791,6 +797,8 @@ def main():
 				"traffic": measured_traffic(k2_bytes),
 				"algorithmic_bytes_per_launch": k2_bytes,
 				"avg_launch_ms": round(k2_ms, 4),
+				"launches_timed": "%d of the %d K2 launches of the timed steps (every %s), HIP events on the launch stream" % (
+					len(events), args.steps * args.pages, {1: "one", 2: "second", 3: "third"}.get(EVENT_EVERY, "%dth" % EVENT_EVERY)),
 			},
 		}
 		if pipeline is not None:
