@@ -1,13 +1,18 @@
 """libogdewarp's deflate writer (csrc/ogd_deflate.h, host code) read back by zlib and by the library's own inflate."""
 import io
+import shutil
+import subprocess
 import zipfile
 import zlib
+from pathlib import Path
 
 import numpy as np
 import pytest
 
 from origami_amd import _shim, synth
 from origami_amd.dewarp import Grid
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _cases():
@@ -141,3 +146,20 @@ def test_checksums_equal_zlibs_over_lengths_and_alignments():
 		bad = bytearray(z)
 		bad[-1] ^= 1  # a wrong Adler-32 is noticed
 		assert lib.ogd_inflate_zlib(bytes(bad), len(bad), out.ctypes.data, out.size, ctypes.byref(n_out)) != 0
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no host compiler")
+def test_deflate_fuzz_under_address_sanitizer(tmp_path):
+	"""tools/deflate_fuzz.cpp: the entropy coder into exact-size heap buffers of every capacity around the stream's
+	size (zlib reads every stream back, short buffers are refused), the SIMD checksums against zlib's; ASan + UBSan."""
+	exe = tmp_path / "deflate_fuzz"
+	build = subprocess.run(
+		["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+			str(ROOT / "tools" / "deflate_fuzz.cpp"), "-lz", "-o", str(exe)], capture_output=True, text=True)
+	if build.returncode != 0:
+		pytest.skip("sanitizer build not available here: %s" % build.stderr[-300:])
+	run = subprocess.run([str(exe), "60"], capture_output=True, text=True, timeout=300)
+	if run.returncode != 0 and "runtime does not come first" in run.stderr:
+		pytest.skip("another preloaded library keeps AddressSanitizer from starting here")
+	assert run.returncode == 0, run.stdout + run.stderr
+	assert "streams read back by zlib" in run.stdout
