@@ -19,7 +19,16 @@ namespace ogd {
 // two rows or plain stores are faster alone but slow that K2 down by more than they gain.
 constexpr int GF_THREADS = 512;
 constexpr int GF_ROWS = 4;
-constexpr int GL_COLS = 496, GL_ROWS = 8;  // grid_fill_lines_kernel's tile; its rows must not exceed the cell size
+#ifndef GL_COLS_V
+#define GL_COLS_V 496
+#endif
+#ifndef GL_ROWS_V
+#define GL_ROWS_V 8
+#endif
+#ifndef GL_NT
+#define GL_NT true  // non-temporal stores
+#endif
+constexpr int GL_COLS = GL_COLS_V, GL_ROWS = GL_ROWS_V;  // grid_fill_lines_kernel's tile; its rows must not exceed the cell size
 #ifndef GL_THREADS
 #define GL_THREADS 256  // 512 is faster alone and slower with the K2 that follows (ogd_grid_lines.h); tools/build_variant_all.sh
 #endif
@@ -114,7 +123,7 @@ int ogd_grid_fill_rows_dev(const float* d_nodes, int h, int w, int s, float sx, 
     // follows (tools/kbench "lines", profiles/r02/m_kbench_k1a_lines.log)
     dim3 lgrid((Wd + 15 + GL_COLS - 1) / GL_COLS, (nrows + GL_ROWS - 1) / GL_ROWS);
     OGD_REQUIRE(lgrid.y <= 65535u, "dense grid too tall");
-    hipLaunchKernelGGL((grid_fill_lines_kernel<GL_COLS, GL_ROWS, true, GL_THREADS>), lgrid, dim3(GL_THREADS), 0, as_stream(stream),
+    hipLaunchKernelGGL((grid_fill_lines_kernel<GL_COLS, GL_ROWS, GL_NT, GL_THREADS>), lgrid, dim3(GL_THREADS), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(d_nodes), h, w, 1.0 / (double)s, sx, sy,
                        reinterpret_cast<float2*>(d_out), y0, y0 + nrows, Wd);
     return check_launch("grid_fill_lines_kernel");

@@ -23,7 +23,9 @@ def main():
 	W, H = bench.PAGE
 	Hd, Wd, h, w = wl["Hd"], wl["Wd"], wl["h"], wl["w"]
 	stream = torch.cuda.current_stream().cuda_stream
-	dense = [wl["dense"]] + [torch.empty_like(wl["dense"]) for _ in range(max(groups) - 1)]
+	dense = list(wl["dense"])
+	while len(dense) < max(groups):
+		dense.append(torch.empty_like(dense[0]))
 	print("%d pages, %d dense grid buffers of %.0f MB" % (n_pages, len(dense), dense[0].numel() * 4 / 1e6), flush=True)
 
 	def k1a(p, buf):
