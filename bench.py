@@ -80,8 +80,8 @@ def measured_traffic(k2_bytes):
 def parse_args():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
-	ap.add_argument("--steps", type=int, default=3)
-	ap.add_argument("--warmup", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=20)
+	ap.add_argument("--warmup", type=int, default=5)
 	ap.add_argument("--pages", type=int, default=64, help="pages per batch and GPU")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-pipeline", action="store_true", help="skip the host-ring pipeline leg (configs[2])")
@@ -727,7 +727,11 @@ def main():
 	events = []
 	elapsed = timed_steps(
 		lambda timed: run_step(torch, lib, check, wl, stream, events if timed else None, side_stream),
-		args.steps, args.warmup, torch.cuda.synchronize, dist, world, dev, between=lambda: verify(torch, wl))
+		args.steps, args.warmup, torch.cuda.synchronize, dist, world, dev)
+	# the oracle check of a page of the batch: AFTER the timed steps (their outputs are still in place) — between
+	# warm-up and timing, as rounds 1 - 2 had it, the second of CPU work let the GPU's clocks fall again, and the
+	# first timed steps ran 3 % below the settled rate (profiles/r03/af_bench_steps.log)
+	verify(torch, wl)
 
 	fused_mps, fused_ms = fused_pass(torch, lib, check, wl, stream, side_stream)
 	if world > 1:
