@@ -41,11 +41,6 @@ PAGE = (6000, 8000)  # (W, H)
 CELL = 25
 N_WARPS = 8  # distinct warps cycled over the pages of a batch (Qhull set-up is ~2 s each)
 N_POLYGONS = 400
-# K2 launches bracketed by HIP events inside the timed steps: every third (3 and GROUP are coprime, so every position
-# of a group is sampled alike).  The brackets are not free — events around every launch make a step 2.8 % longer
-# (10.64 against 10.36 ms, profiles/r03/ad_bench_events.log) and the K2 they time 0.6 us shorter, because a bracketed
-# launch cannot begin under the tail of the one before it.
-EVENT_EVERY = int(os.environ.get("BENCH_EVENT_EVERY", "3"))
 GROUP = int(os.environ.get("BENCH_GROUP", "8"))  # pages per group of a step: K1a for the group, then K2 for it (run_step)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 K2_KERNEL = "ogd::remap_u8_wave_kernel<1, 1, 16, 2, 4096, ogd::MapGlobal>"
@@ -162,24 +157,26 @@ def run_step(torch, lib, check, wl, stream, events=None, side_stream=None):
 		for p in group:
 			wp = wl["warps"][p % len(wl["warps"])]
 			check(lib.ogd_grid_fill_dev(wp["nodes_d"].data_ptr(), h, w, CELL, 1.0, 1.0, dense[p - g0].data_ptr(), stream))
+		# the group's K2 launches between ONE pair of HIP events: the average launch duration is their span divided by
+		# their number (round 3 began with a pair around every launch: the brackets cost the step 2.8 %, and a launch
+		# between two marker packets reads ~2.5 us longer than the kernel trace shows it, ad_bench_events.log)
+		if events is not None:
+			e0 = torch.cuda.Event(enable_timing=True)
+			e1 = torch.cuda.Event(enable_timing=True)
+			e0.record()
 		for p in group:
 			wp = wl["warps"][p % len(wl["warps"])]
 			poly = wl["polys"][p]
-			ev = events is not None and p % EVENT_EVERY == 0
-			if ev:
-				e0 = torch.cuda.Event(enable_timing=True)
-				e1 = torch.cuda.Event(enable_timing=True)
-				e0.record()
 			check(lib.ogd_remap_u8_dev(
 				wl["pages"][p].data_ptr(), H, W, 1, W, dense[p - g0].data_ptr(), Hd, Wd, wl["outs"][p].data_ptr(), Wd, 1, stream))
-			if ev:
-				e1.record()
-				events.append((e0, e1))
 			# K3 depends on nothing K1a / K2 produce: it runs on its own stream and fills the gaps (on the main stream
-			# after the group's K2 launches a step takes 5 % longer; beside the K1a launches the same: ac_k3_modes.log)
+			# after the group's K2 launches a step takes 5 % longer; beside the K1a launches the same: ab_bench_group.log)
 			check(lib.ogd_tri_eval_ragged_dev(
 				wp["inner"].handle, wp["extra"].handle, wp["bounds"].ctypes.data, poly["q"].data_ptr(),
 				poly["off"].data_ptr(), poly["nrings"], poly["out"].data_ptr(), side_stream or stream))
+		if events is not None:
+			e1.record()
+			events.append((e0, e1, len(group)))
 
 
 def fused_pass(torch, lib, check, wl, stream, side_stream, repeats=2):
@@ -326,11 +323,18 @@ def pipeline_leg(torch, wl, n_jobs, barrier, streams, slots=3):
 	return elapsed, up, down
 
 
-def _event_time(torch, launch, iters, warm=3):
-	"""Average duration in ms of `launch` (which enqueues on torch's current stream) by HIP events on that stream."""
+def _event_time(torch, launch, iters, warm=3, settle_s=0.03):
+	"""Average duration in ms of `launch` (which enqueues on torch's current stream) by HIP events on that stream.
+	The legs check their outputs on the CPU first, and a device that has been idle for a second starts the next
+	kernels below its settled clock (main()): launches are repeated for settle_s seconds before the timed ones."""
 	for _ in range(warm):
 		launch()
 	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	while time.perf_counter() - t0 < settle_s:
+		for _ in range(4):
+			launch()
+		torch.cuda.synchronize()
 	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 	e0.record()
 	for _ in range(iters):
@@ -761,7 +765,7 @@ def main():
 	W, H = PAGE
 	mp_per_step = args.pages * Hd * Wd / 1e6
 	value = world * mp_per_step * args.steps / elapsed
-	k2_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+	k2_ms = float(sum(a.elapsed_time(b) for a, b, _ in events) / sum(n for _, _, n in events))
 	k2_bytes = Hd * Wd * (8 + 1) + H * W * 1
 	achieved = k2_bytes / (k2_ms * 1e-3) / 1e9
 
@@ -801,8 +805,8 @@ def main():
 				"traffic": measured_traffic(k2_bytes),
 				"algorithmic_bytes_per_launch": k2_bytes,
 				"avg_launch_ms": round(k2_ms, 4),
-				"launches_timed": "%d of the %d K2 launches of the timed steps (every %s), HIP events on the launch stream" % (
-					len(events), args.steps * args.pages, {1: "one", 2: "second", 3: "third"}.get(EVENT_EVERY, "%dth" % EVENT_EVERY)),
+				"launches_timed": "all %d K2 launches of the timed steps, one pair of HIP events on the launch stream around the %d launches of each group" % (
+					sum(n for _, _, n in events), GROUP),
 			},
 		}
 		if pipeline is not None:
