@@ -244,7 +244,7 @@ class Processor:
 					yield index, page
 
 	def _start_prefetch(self, page, files):
-		if type(self).prefetch is Processor.prefetch:
+		if type(self).prefetch is Processor.prefetch or os.environ.get("OGD_PREFETCH", "1") == "0":
 			return None
 		if self._prefetcher is None:
 			self._prefetcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prefetch")
