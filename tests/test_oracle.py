@@ -430,3 +430,45 @@ def test_dense_grid_half_pixel_convention_agrees_with_torch_interpolate(shape, c
 		c = (cell - 1) // 2
 		assert np.array_equal(got[c::cell, c::cell], nodes)
 	assert np.array_equal(got[0, 0], nodes[0, 0]) and np.array_equal(got[-1, -1], nodes[-1, -1])
+
+
+def test_remap_convention_against_scipy_map_coordinates():
+	"""An INDEPENDENT implementation of what cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) means — it does not pin cv2
+	(PARITY UNPINNED stays): scipy.ndimage.map_coordinates(order=1, mode="grid-constant") samples the image at
+	(y, x) in pixel-index coordinates with zeros outside, in float64.  cv2's arithmetic differs in the last bits by
+	design — coordinates rounded to 1/32 px, 15-bit weights — so on an image whose neighbouring pixels differ by up to
+	g grey levels the two may differ by g / 64 + 1; what the comparison shows is the convention: sample positions at
+	pixel centres named by integers, zeros (not replicated edges) outside.  A map shifted by half a pixel, the usual
+	way to get this wrong, is an order of magnitude further off."""
+	import scipy.ndimage
+	rng = np.random.default_rng(5)
+	H, W = 240, 320
+	yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+	smooth = 128 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 40 * np.sin((xx + yy) / 23.0)
+	img = np.clip(smooth + rng.normal(0, 2, size=(H, W)), 0, 255).astype(np.uint8)
+	Hd, Wd = 260, 350  # the map reaches past every edge of the image
+	my, mx = np.mgrid[0:Hd, 0:Wd].astype(np.float64)
+	x = (mx - 12) * 0.97 + 6 * np.sin(my / 40.0) + rng.uniform(0, 1, size=(Hd, Wd))
+	y = (my - 9) * 1.02 + 5 * np.cos(mx / 55.0) + rng.uniform(0, 1, size=(Hd, Wd))
+	dense = np.stack([x, y], axis=-1).astype(np.float32)
+	got = ocv.remap_u8(img, dense).astype(np.float64)
+	fx, fy = dense[:, :, 0].astype(np.float64), dense[:, :, 1].astype(np.float64)
+
+	def sampled(dx, dy):
+		return scipy.ndimage.map_coordinates(img.astype(np.float64), [fy + dy, fx + dx], order=1, mode="grid-constant", cval=0.0)
+
+	ref = sampled(0.0, 0.0)
+	# the largest step between neighbouring pixels bounds what 1/64 px of coordinate rounding can do
+	g = max(np.abs(np.diff(img.astype(np.int32), axis=0)).max(), np.abs(np.diff(img.astype(np.int32), axis=1)).max())
+	inside = (fx >= 0) & (fx <= W - 1) & (fy >= 0) & (fy <= H - 1)
+	diff = np.abs(got - ref)
+	assert diff[inside].max() <= 2 * g / 64.0 + 1.0  # x and y each contribute up to g / 64
+	assert diff[inside].mean() < 0.5
+	# outside the image: zeros, fading in over the last pixel (an edge-replicating border would give ~128 there)
+	far = (fx < -1) | (fx > W) | (fy < -1) | (fy > H)
+	assert far.any() and got[far].max() == 0 and ref[far].max() == 0
+	rim = ~inside & ~far
+	assert rim.any() and np.abs(got[rim] - ref[rim]).max() <= 255 / 32.0 + 1.0  # the step to the zero border is up to 255
+	# the wrong convention is far away: half a pixel off in either axis
+	for dx, dy in ((0.5, 0.0), (0.0, 0.5), (-0.5, -0.5)):
+		assert np.abs(got - sampled(dx, dy))[inside].mean() > 5 * diff[inside].mean()
